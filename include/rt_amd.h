@@ -152,6 +152,16 @@ int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32,
 /* Number of rows selected by p (size of the output in rows).                       */
 int rt_rows_selected(const rt_render_params* p);
 
+/* Parity probe: runs only the ray-tree part for the rows selected by p and returns,
+ * for every nearest-hit query (scene_settings.py:19), what find_nearest_intersection
+ * returns in the reference: surface index (-1 = miss), t, hit point, normal -- in
+ * float64, so tests can require bit equality -- plus the own-surface flags handed to
+ * the shading kernel.  Arrays hold `capacity` records (P, n: 3 doubles each); *count
+ * receives the number of queries (records beyond capacity are dropped).             */
+int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, uint32_t* pixel,
+                  uint32_t* node, int32_t* surf, double* t, double* P, double* n, uint32_t* flags,
+                  uint32_t* count);
+
 /* Jitter stream contract, exported so tests can pin host == device == oracle.
  * Writes the two 24-bit integers of sample s of grid (seed,pixel,node,light).       */
 void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s,

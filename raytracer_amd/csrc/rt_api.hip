@@ -1,0 +1,517 @@
+// rt_api.hip -- host side of librt_amd.so: the C ABI of include/rt_amd.h.
+//
+// Owns the per-GPU context, derives the scene constants in float64 with the
+// reference's rounding (camera basis camera.py:14-16, unit plane normals
+// infinite_plane.py:8, box corners cube.py:32-34, r*r and r**2 sphere.py:38/:93),
+// and drives the wavefront pipeline for a frame:
+//
+//   for each row band:   depth 0: camera rays + nearest hit  -> shade queue, ray queue 1
+//                        depth d: ray queue d -> nearest hit -> shade queue, ray queue d+1
+//                        shade : every shaded hit of the band, all depths, ONE launch
+//                        resolve: accumulators -> clip*255 -> float32 / uint8 rows
+//
+// The launch sequence is fixed (max_recursions trace launches per band whatever the
+// queues hold; kernels read their item counts from device memory), so there is no
+// host round trip inside a band; the only synchronisation is at the end of a band,
+// where the overflow counters are read.  A band whose ray tree outgrows the queues
+// is retried with fewer rows.
+#include "rt_device.h"
+#include "../../include/rt_amd.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+struct v3 { double x, y, z; };
+inline v3 sub(v3 a, v3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline v3 divs(v3 a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+inline double dotb(v3 a, v3 b) { return std::fma(a.z, b.z, std::fma(a.y, b.y, a.x * b.x)); }
+inline v3 cross(v3 a, v3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v : divs(v, n); }
+
+constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
+constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
+
+}  // namespace
+
+struct rt_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int n_cu = 256;
+    int shade_blocks_per_cu = 4;
+
+    // scene
+    bool has_scene = false;
+    int S = 0, M = 0, L = 0, N = 1, R = 0;
+    float bg[3] = {0, 0, 0};
+    CameraD cam{};
+    SurfD* d_surf = nullptr;
+    SurfF* d_surff = nullptr;
+    MatF* d_mat = nullptr;
+    LightF* d_light = nullptr;
+    double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
+    double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
+
+    // frame buffers, sized for band_capacity pixels
+    size_t band_capacity = 0;        // pixels
+    size_t max_band_pixels = 3840u * 2160u;
+    RayQueue rq[2]{};
+    ShadeQueue sq{};
+    HitDebug dbg{};
+    double* d_accum = nullptr;
+    unsigned long long* d_counters = nullptr;
+    uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug
+    int32_t* d_row_y = nullptr;
+    size_t row_y_cap = 0;
+    float* d_out_f32 = nullptr;
+    uint8_t* d_out_u8 = nullptr;
+    size_t out_cap = 0;              // values
+    void* arena = nullptr;           // one allocation behind all queue arrays
+    hipEvent_t ev[5]{};
+};
+
+namespace {
+
+int fail(rt_handle* h, int code, const std::string& msg) {
+    if (h) h->err = msg;
+    return code;
+}
+#define HIP_TRY(h, expr)                                                                          \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(h, e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_DEVICE,                \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+    } while (0)
+
+void free_frame_buffers(rt_handle* h) {
+    if (h->arena) (void)hipFree(h->arena);
+    h->arena = nullptr;
+    h->band_capacity = 0;
+}
+
+// carve the SoA queues out of one arena
+int ensure_band_capacity(rt_handle* h, size_t pixels) {
+    if (pixels <= h->band_capacity) return RT_OK;
+    free_frame_buffers(h);
+    const size_t rcap = pixels * kRayFactor, scap = pixels * kShadeFactor;
+    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
+    size_t bytes = 0;
+    bytes += 2 * (6 * al(rcap * 8) + 5 * al(rcap * 4));  // two ray queues
+    bytes += 16 * al(scap * 4);                         // shade queue
+    bytes += al(pixels * 3 * 8);                        // accumulators
+    void* base = nullptr;
+    hipError_t e = hipMalloc(&base, bytes);
+    if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes for frame queues failed");
+    h->arena = base;
+    char* p = (char*)base;
+    auto take = [&](size_t b) { void* r = p; p += al(b); return r; };
+    for (int q = 0; q < 2; ++q) {
+        RayQueue& r = h->rq[q];
+        r.ox = (double*)take(rcap * 8); r.oy = (double*)take(rcap * 8); r.oz = (double*)take(rcap * 8);
+        r.dx = (double*)take(rcap * 8); r.dy = (double*)take(rcap * 8); r.dz = (double*)take(rcap * 8);
+        r.tr = (float*)take(rcap * 4); r.tg = (float*)take(rcap * 4); r.tb = (float*)take(rcap * 4);
+        r.pixel = (uint32_t*)take(rcap * 4); r.node = (uint32_t*)take(rcap * 4);
+        r.count = h->d_qcounts + q;
+        r.capacity = (uint32_t)rcap;
+    }
+    ShadeQueue& s = h->sq;
+    float** fp[12] = {&s.px, &s.py, &s.pz, &s.nx, &s.ny, &s.nz, &s.vx, &s.vy, &s.vz, &s.wr, &s.wg, &s.wb};
+    for (auto f : fp) *f = (float*)take(scap * 4);
+    s.pixel = (uint32_t*)take(scap * 4); s.gpixel = (uint32_t*)take(scap * 4);
+    s.node = (uint32_t*)take(scap * 4); s.meta = (uint32_t*)take(scap * 4);
+    s.count = h->d_qcounts + 2;
+    s.capacity = (uint32_t)scap;
+    h->d_accum = (double*)take(pixels * 3 * 8);
+    h->band_capacity = pixels;
+    return RT_OK;
+}
+
+int validate_params(rt_handle* h, const rt_render_params* p) {
+    if (!p || p->struct_size != sizeof(rt_render_params)) return fail(h, RT_ERR_INVALID, "rt_render_params: bad struct_size");
+    if (p->width < 1 || p->height < 1) return fail(h, RT_ERR_INVALID, "width and height must be >= 1");
+    if ((int64_t)p->width * p->height > 0x7FFFFFFFll) return fail(h, RT_ERR_INVALID, "frame has more than 2^31 pixels");
+    if (p->row_begin < 0 || p->row_end > p->height || p->row_begin > p->row_end)
+        return fail(h, RT_ERR_INVALID, "row range outside the frame");
+    if (p->stripe_rows < 1 || p->stripe_count < 1 || p->stripe_index < 0 || p->stripe_index >= p->stripe_count)
+        return fail(h, RT_ERR_INVALID, "bad stripe selection");
+    return RT_OK;
+}
+
+void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
+    rows.clear();
+    for (int y = p->row_begin; y < p->row_end; ++y)
+        if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) rows.push_back(y);
+}
+
+struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
+
+// enqueue one band; rows[r0..r1) ; outputs are device pointers to the band's first value (may be null)
+int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n_rows, float* d_f32, uint8_t* d_u8,
+             hipStream_t st, bool debug, BandResult* res) {
+    const size_t pixels = (size_t)n_rows * p->width;
+    HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * 4, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_accum, 0, sizeof(double) * 3 * pixels, st));
+
+    FrameParams fp{};
+    fp.width = p->width; fp.height = p->height; fp.band_rows = n_rows;
+    fp.max_rec = h->R; fp.n_shadow = h->N; fp.n_surfaces = h->S; fp.n_lights = h->L;
+    fp.seed_key = rt_seed_key(p->seed);
+    fp.bg[0] = h->bg[0]; fp.bg[1] = h->bg[1]; fp.bg[2] = h->bg[2];
+    fp.row_y = h->d_row_y;
+
+    HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    const int max_blocks = h->n_cu * 8;
+    const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
+    for (int d = 0; d < depths; ++d) {
+        TraceArgs ta{};
+        ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat;
+        ta.in = h->rq[d & 1]; ta.out = h->rq[(d + 1) & 1];
+        ta.shade = h->sq;
+        ta.dbg = debug ? h->dbg : HitDebug{};
+        ta.accum = h->d_accum; ta.counters = h->d_counters; ta.depth = d;
+        // the queue this depth fills must start empty (it was the input two depths ago)
+        HIP_TRY(h, hipMemsetAsync(ta.out.count, 0, sizeof(uint32_t), st));
+        int blocks = max_blocks;
+        if (d == 0) blocks = (int)std::min<size_t>((pixels + 255) / 256, (size_t)max_blocks);
+        rt_launch_trace(ta, std::max(blocks, 1), st);
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    if (!debug) {
+        ShadeArgs sa{};
+        sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq;
+        sa.accum = h->d_accum; sa.counters = h->d_counters;
+        rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
+    }
+    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels * 3, d_f32, d_u8, st);
+    HIP_TRY(h, hipEventRecord(h->ev[3], st));
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipStreamSynchronize(st));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, h->ev[0], h->ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, h->ev[1], h->ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, h->ev[2], h->ev[3]));
+    return RT_OK;
+}
+
+int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats) {
+    std::vector<int32_t> rows;
+    selected_rows(p, rows);
+    rt_stats s{};
+    s.rows_rendered = rows.size();
+    if (rows.empty()) { if (stats) *stats = s; return RT_OK; }
+    if (rows.size() > h->row_y_cap) {
+        if (h->d_row_y) (void)hipFree(h->d_row_y);
+        h->d_row_y = nullptr; h->row_y_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
+        h->row_y_cap = rows.size();
+    }
+    const size_t W = (size_t)p->width;
+    size_t band_rows = std::max<size_t>(1, std::min(rows.size(), h->max_band_pixels / W));
+    int rc = ensure_band_capacity(h, band_rows * W);
+    if (rc != RT_OK) return rc;
+
+    hipEvent_t e_begin = h->ev[4];
+    HIP_TRY(h, hipEventRecord(e_begin, st));
+    hipEvent_t e_end;
+    HIP_TRY(h, hipEventCreate(&e_end));
+    size_t r0 = 0;
+    while (r0 < rows.size()) {
+        size_t n = std::min(band_rows, rows.size() - r0);
+        BandResult br{};
+        rc = run_band(h, p, rows.data() + r0, (int)n, d_f32 ? d_f32 + r0 * W * 3 : nullptr,
+                      d_u8 ? d_u8 + r0 * W * 3 : nullptr, st, false, &br);
+        if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+        if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) {
+            if (n == 1) {
+                (void)hipEventDestroy(e_end);
+                return fail(h, RT_ERR_QUEUE, "ray tree of a single row exceeds the queue capacity");
+            }
+            band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
+            continue;
+        }
+        s.primary_rays += br.c[CNT_PRIMARY]; s.secondary_rays += br.c[CNT_SECONDARY];
+        s.depth_cut += br.c[CNT_DEPTH_CUT]; s.shaded_points += br.c[CNT_SHADED];
+        s.ms_trace += br.ms_trace; s.ms_shade += br.ms_shade; s.ms_resolve += br.ms_resolve;
+        s.bands += 1;
+        r0 += n;
+    }
+    HIP_TRY(h, hipEventRecord(e_end, st));
+    HIP_TRY(h, hipEventSynchronize(e_end));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, e_begin, e_end));
+    (void)hipEventDestroy(e_end);
+    s.ms_total = ms;
+    s.shadow_rays = (uint64_t)std::llround((double)s.shaded_points * h->shadow_rays_per_hit);
+    s.flop_shade = (double)s.shaded_points * h->flop_per_hit;
+    if (stats) *stats = s;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_create(int device, rt_handle** out) {
+    if (!out) return RT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return RT_ERR_DEVICE;
+    rt_handle* h = new rt_handle();
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return RT_ERR_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess &&
+              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * 4) == hipSuccess;
+    for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    if (!ok) { rt_destroy(h); return RT_ERR_DEVICE; }
+    *out = h;
+    return RT_OK;
+}
+
+void rt_destroy(rt_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_frame_buffers(h);
+    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_counters,
+                    (void*)h->d_qcounts, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
+                    (void*)h->dbg.gpixel})
+        if (p) (void)hipFree(p);
+    for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* rt_last_error(const rt_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
+    if (!h) return RT_ERR_INVALID;
+    if (!d || d->struct_size != sizeof(rt_scene_desc) || d->abi_version != RT_ABI_VERSION)
+        return fail(h, RT_ERR_INVALID, "rt_scene_desc: bad struct_size / abi_version");
+    if (d->n_surfaces < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(h, RT_ERR_INVALID, "negative count");
+    if (d->n_surfaces >= (1 << 24)) return fail(h, RT_ERR_UNSUPPORTED, "more than 2^24-1 surfaces");
+    if (d->n_shadow < 1) return fail(h, RT_ERR_INVALID, "n_shadow must be >= 1");
+    if (d->n_shadow > 1024) return fail(h, RT_ERR_UNSUPPORTED, "n_shadow above 1024");
+    if (d->max_rec < 0 || d->max_rec > 31) return fail(h, RT_ERR_UNSUPPORTED, "max_rec must be in [0, 31] (32-bit ray-tree node ids)");
+    if (d->n_surfaces > 0 && (!d->surf_type || !d->surf_param || !d->surf_material)) return fail(h, RT_ERR_INVALID, "null surface arrays");
+    if (d->n_surfaces > 0 && d->n_materials < 1) return fail(h, RT_ERR_INVALID, "surfaces without materials");
+    if ((d->n_materials > 0 && !d->mat_param) || (d->n_lights > 0 && !d->light_param)) return fail(h, RT_ERR_INVALID, "null material / light arrays");
+    HIP_TRY(h, hipSetDevice(h->device));
+
+    const int S = d->n_surfaces, M = d->n_materials, L = d->n_lights;
+    std::vector<MatF> mats((size_t)std::max(M, 1));
+    std::memset(mats.data(), 0, sizeof(MatF) * mats.size());
+    for (int m = 0; m < M; ++m) {
+        const double* q = d->mat_param;
+        MatF& t = mats[m];
+        for (int c = 0; c < 3; ++c) {
+            t.kd[c] = (float)q[(0 + c) * M + m]; t.ks[c] = (float)q[(3 + c) * M + m]; t.kr[c] = (float)q[(6 + c) * M + m];
+        }
+        t.shin = (float)q[9 * M + m];
+        t.transp = (float)q[10 * M + m];
+        // gates are evaluated on the float64 inputs (ray_tracer.py:192, :226)
+        t.has_refl = (q[6 * M + m] > 0 || q[7 * M + m] > 0 || q[8 * M + m] > 0) ? 1 : 0;
+        if (q[10 * M + m] > 0 && t.transp == 0.f) t.transp = 1e-45f;
+    }
+    std::vector<SurfD> sd((size_t)std::max(S, 1));
+    std::vector<SurfF> sf((size_t)std::max(S, 1));
+    std::memset(sd.data(), 0, sizeof(SurfD) * sd.size());
+    std::memset(sf.data(), 0, sizeof(SurfF) * sf.size());
+    double test_flops = 0; bool any_box = false;
+    for (int s = 0; s < S; ++s) {
+        int type = d->surf_type[s], mat = d->surf_material[s];
+        if (mat < 0 || mat >= M) return fail(h, RT_ERR_INVALID, "surface " + std::to_string(s) + ": material index out of range");
+        v3 p = {d->surf_param[0 * S + s], d->surf_param[1 * S + s], d->surf_param[2 * S + s]};
+        double p3 = d->surf_param[3 * S + s];
+        SurfD& a = sd[s]; SurfF& f = sf[s];
+        a.mat = f.mat = mat;
+        f.transp = mats[mat].transp;
+        if (type == RT_SURF_SPHERE) {
+            a.type = f.type = RT_SURF_SPHERE;
+            a.d[0] = p.x; a.d[1] = p.y; a.d[2] = p.z; a.d[3] = p3;
+            a.d[4] = p3 * p3;            // sphere.py:38
+            a.d[5] = std::pow(p3, 2.0);  // sphere.py:93 (Python float ** 2)
+            f.a = make_float4((float)p.x, (float)p.y, (float)p.z, (float)(p3 * p3));
+            test_flops += 20;
+        } else if (type == RT_SURF_PLANE || type == RT_SURF_PLANE_RAW) {
+            if (type == RT_SURF_PLANE_RAW) p = divs(p, std::sqrt(dotb(p, p)));  // infinite_plane.py:8
+            a.type = f.type = RT_SURF_PLANE;
+            a.d[0] = p.x; a.d[1] = p.y; a.d[2] = p.z; a.d[3] = p3;
+            f.a = make_float4((float)p.x, (float)p.y, (float)p.z, (float)p3);
+            test_flops += 12;
+        } else if (type == RT_SURF_BOX) {
+            a.type = f.type = RT_SURF_BOX;
+            double half = p3 / 2.0;  // cube.py:32-34
+            a.d[0] = p.x - half; a.d[1] = p.y - half; a.d[2] = p.z - half;
+            a.d[3] = p.x + half; a.d[4] = p.y + half; a.d[5] = p.z + half;
+            f.a = make_float4((float)a.d[0], (float)a.d[1], (float)a.d[2], 0.f);
+            f.b = make_float4((float)a.d[3], (float)a.d[4], (float)a.d[5], 0.f);
+            test_flops += 24; any_box = true;
+        } else {
+            return fail(h, RT_ERR_INVALID, "surface " + std::to_string(s) + ": unknown type");
+        }
+    }
+    if (any_box) test_flops += 3;
+    std::vector<LightF> lights((size_t)std::max(L, 1));
+    std::memset(lights.data(), 0, sizeof(LightF) * lights.size());
+    double rays_per_hit = 0;
+    for (int l = 0; l < L; ++l) {
+        const double* q = d->light_param;
+        LightF& t = lights[l];
+        for (int c = 0; c < 3; ++c) { t.pos[c] = (float)q[c * L + l]; t.col[c] = (float)q[(3 + c) * L + l]; }
+        t.spec = (float)q[6 * L + l]; t.shadow = (float)q[7 * L + l]; t.radius = (float)q[8 * L + l];
+        t.point_path = (q[7 * L + l] == 0 || d->n_shadow == 1) ? 1 : 0;  // ray_tracer.py:36
+        rays_per_hit += t.point_path ? 1.0 : (double)d->n_shadow * d->n_shadow;
+    }
+
+    // Camera.__init__ (camera.py:14-16)
+    v3 pos = {d->cam_pos[0], d->cam_pos[1], d->cam_pos[2]};
+    v3 look = {d->cam_look_at[0], d->cam_look_at[1], d->cam_look_at[2]};
+    v3 uph = {d->cam_up[0], d->cam_up[1], d->cam_up[2]};
+    v3 fwd = normalize(sub(look, pos));
+    v3 right = normalize(cross(fwd, uph));
+    v3 up = normalize(cross(right, fwd));
+    CameraD cam{};
+    cam.pos[0] = pos.x; cam.pos[1] = pos.y; cam.pos[2] = pos.z;
+    cam.fwd[0] = fwd.x; cam.fwd[1] = fwd.y; cam.fwd[2] = fwd.z;
+    cam.right[0] = right.x; cam.right[1] = right.y; cam.right[2] = right.z;
+    cam.up[0] = up.x; cam.up[1] = up.y; cam.up[2] = up.z;
+    cam.sdist = d->cam_screen_dist; cam.swidth = d->cam_screen_width;
+
+    for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light}) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    h->has_scene = false;
+    HIP_TRY(h, hipMalloc(&h->d_surf, sizeof(SurfD) * sd.size()));
+    HIP_TRY(h, hipMalloc(&h->d_surff, sizeof(SurfF) * sf.size()));
+    HIP_TRY(h, hipMalloc(&h->d_mat, sizeof(MatF) * mats.size()));
+    HIP_TRY(h, hipMalloc(&h->d_light, sizeof(LightF) * lights.size()));
+    HIP_TRY(h, hipMemcpy(h->d_surf, sd.data(), sizeof(SurfD) * sd.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_surff, sf.data(), sizeof(SurfF) * sf.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_mat, mats.data(), sizeof(MatF) * mats.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_light, lights.data(), sizeof(LightF) * lights.size(), hipMemcpyHostToDevice));
+    h->S = S; h->M = M; h->L = L; h->N = d->n_shadow; h->R = d->max_rec;
+    for (int c = 0; c < 3; ++c) h->bg[c] = (float)d->background[c];
+    h->cam = cam;
+    h->shadow_rays_per_hit = rays_per_hit;
+    // algorithmic FP32 flop per shaded hit: per shadow ray the surface tests + 26 for building the
+    // ray; per (hit, light) 30 for the sampling basis + 52 for the Phong terms; 12 for the blend
+    h->flop_per_hit = rays_per_hit * (test_flops + 26.0) + L * 82.0 + 12.0;
+    h->has_scene = true;
+    return RT_OK;
+}
+
+int rt_rows_selected(const rt_render_params* p) {
+    if (!p || p->stripe_rows < 1 || p->stripe_count < 1) return RT_ERR_INVALID;
+    int n = 0;
+    for (int y = p->row_begin; y < p->row_end; ++y)
+        if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) ++n;
+    return n;
+}
+
+int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8, void* stream, rt_stats* stats) {
+    if (!h) return RT_ERR_INVALID;
+    if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render before rt_set_scene");
+    int rc = validate_params(h, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return render_impl(h, p, (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, stats);
+}
+
+int rt_render(rt_handle* h, const rt_render_params* p, float* host_rgb_f32, uint8_t* host_rgb_u8, rt_stats* stats) {
+    if (!h) return RT_ERR_INVALID;
+    if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render before rt_set_scene");
+    int rc = validate_params(h, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    const size_t values = (size_t)rt_rows_selected(p) * p->width * 3;
+    if (values > h->out_cap) {
+        if (h->d_out_f32) (void)hipFree(h->d_out_f32);
+        if (h->d_out_u8) (void)hipFree(h->d_out_u8);
+        h->d_out_f32 = nullptr; h->d_out_u8 = nullptr; h->out_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_out_f32, values * sizeof(float)));
+        HIP_TRY(h, hipMalloc(&h->d_out_u8, values));
+        h->out_cap = values;
+    }
+    rc = render_impl(h, p, host_rgb_f32 ? h->d_out_f32 : nullptr, host_rgb_u8 ? h->d_out_u8 : nullptr, h->stream, stats);
+    if (rc != RT_OK) return rc;
+    if (host_rgb_f32 && values) HIP_TRY(h, hipMemcpy(host_rgb_f32, h->d_out_f32, values * sizeof(float), hipMemcpyDeviceToHost));
+    if (host_rgb_u8 && values) HIP_TRY(h, hipMemcpy(host_rgb_u8, h->d_out_u8, values, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, uint32_t* pixel, uint32_t* node, int32_t* surf,
+                  double* t, double* P, double* n, uint32_t* flags, uint32_t* count) {
+    if (!h) return RT_ERR_INVALID;
+    if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_debug_hits before rt_set_scene");
+    int rc = validate_params(h, p);
+    if (rc != RT_OK) return rc;
+    if (!capacity || !count) return fail(h, RT_ERR_INVALID, "capacity / count");
+    HIP_TRY(h, hipSetDevice(h->device));
+    std::vector<int32_t> rows;
+    selected_rows(p, rows);
+    *count = 0;
+    if (rows.empty()) return RT_OK;
+    const size_t pixels = rows.size() * (size_t)p->width;
+    if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "debug probe is limited to one band");
+    if (rows.size() > h->row_y_cap) {
+        if (h->d_row_y) (void)hipFree(h->d_row_y);
+        h->d_row_y = nullptr; h->row_y_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
+        h->row_y_cap = rows.size();
+    }
+    rc = ensure_band_capacity(h, pixels);
+    if (rc != RT_OK) return rc;
+    // debug arrays: one allocation, freed with the handle or on the next probe
+    if (h->dbg.gpixel) (void)hipFree(h->dbg.gpixel);
+    h->dbg = HitDebug{};
+    const size_t c = capacity;
+    char* base = nullptr;
+    HIP_TRY(h, hipMalloc(&base, c * (4 + 4 + 4 + 4 + 8 + 24 + 24) + 1024));
+    HitDebug g{};
+    g.gpixel = (uint32_t*)base; g.node = g.gpixel + c; g.surf = (int32_t*)(g.node + c); g.flags = (uint32_t*)(g.surf + c);
+    g.t = (double*)(base + (c * 16 + 255) / 256 * 256); g.P = g.t + c; g.n = g.P + 3 * c;
+    g.count = h->d_qcounts + 3; g.capacity = capacity;
+    h->dbg = g;
+    BandResult br{};
+    rc = run_band(h, p, rows.data(), (int)rows.size(), nullptr, nullptr, h->stream, true, &br);
+    if (rc != RT_OK) return rc;
+    if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) return fail(h, RT_ERR_QUEUE, "debug probe overflowed the queues");
+    uint32_t got = 0;
+    HIP_TRY(h, hipMemcpy(&got, g.count, 4, hipMemcpyDeviceToHost));
+    *count = got;
+    const size_t m = std::min<size_t>(got, c);
+    if (m) {
+        HIP_TRY(h, hipMemcpy(pixel, g.gpixel, m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(node, g.node, m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(surf, g.surf, m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(flags, g.flags, m * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(t, g.t, m * 8, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(P, g.P, m * 24, hipMemcpyDeviceToHost));
+        HIP_TRY(h, hipMemcpy(n, g.n, m * 24, hipMemcpyDeviceToHost));
+    }
+    return RT_OK;
+}
+
+void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s, uint32_t* u24, uint32_t* v24) {
+    uint32_t u, v;
+    rt_sample_bits(rt_grid_key(rt_seed_key(seed), pixel, node, light), s, u, v);
+    if (u24) *u24 = u;
+    if (v24) *v24 = v;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// rt_device.h -- structures shared by the host orchestration (rt_api.cpp) and the
+// gfx950 kernels (rt_trace.hip, rt_shade.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_EPS 1e-6   // /root/reference/utils.py:6
+#define RT_EPSF 1e-6f
+
+// ---- float64 surface record used by the ray-tree kernel -------------------------
+// One 64-byte record per surface, file order.  All lanes of a wave test the same
+// surface at the same time, so LDS reads of a record are broadcasts.
+//   sphere: d[0..2] centre, d[3] radius, d[4] r*r, d[5] pow(r,2)
+//   plane : d[0..2] unit normal, d[3] offset
+//   box   : d[0..2] min corner, d[3..5] max corner
+struct SurfD {
+    double d[7];
+    int32_t type;  // RT_SURF_SPHERE / PLANE / BOX (PLANE_RAW is resolved on upload)
+    int32_t mat;
+};
+
+// ---- float32 surface record used by the shading kernel --------------------------
+//   sphere: a = (cx, cy, cz, r*r)
+//   plane : a = (nx, ny, nz, offset)
+//   box   : a = (minx, miny, minz, -), b = (maxx, maxy, maxz, -)
+struct SurfF {
+    float4 a;
+    float4 b;       // box only
+    int32_t type;
+    float transp;   // transparency of the surface's material (shadow attenuation)
+    int32_t mat;
+    int32_t pad;
+};
+
+struct MatF {
+    float kd[3], ks[3], kr[3];
+    float shin, transp;
+    int32_t has_refl;
+};
+
+struct LightF {
+    float pos[3], col[3];
+    float spec, shadow, radius;
+    int32_t point_path;  // 1: single-ray path (N == 1 or shadow_intensity == 0, ray_tracer.py:36)
+};
+
+struct CameraD {
+    double pos[3], fwd[3], right[3], up[3];
+    double sdist, swidth;
+};
+
+// ---- queues (structure of arrays in HBM; one slot per ray / per shaded hit) -----
+struct RayQueue {
+    double *ox, *oy, *oz, *dx, *dy, *dz;  // float64 origin / direction (the bit-faithful chain)
+    float *tr, *tg, *tb;                  // throughput: product of kr / transparency up the tree
+    uint32_t *pixel;                      // LOCAL pixel index inside the band
+    uint32_t *node;                       // ray-tree node id (1 = camera ray, 2k reflect, 2k+1 transmit)
+    uint32_t* count;                      // device counter
+    uint32_t capacity;
+};
+
+// flags of a shaded hit: how the reference's float64 arithmetic resolves shadow rays that
+// start on the hit primitive and point into it (decided in float64 by the ray-tree kernel)
+#define HF_CBATCH_POS 1u   // sphere: sum(oc^2) - r**2 > 0   (sphere.py:93)  -> inward samples NOT blocked
+#define HF_CDOT_POS 2u     // sphere: dot(oc,oc) - r*r > 0    (sphere.py:38)  -> same, single-ray path
+#define HF_BOX_OUTSIDE 4u  // box: hit point lies strictly outside its face plane -> single-ray path not blocked
+#define HF_NO_OWN 8u       // degenerate hit (zero normal): no own-surface rule
+
+struct ShadeQueue {
+    float *px, *py, *pz;   // hit point
+    float *nx, *ny, *nz;   // stored (outward) normal
+    float *vx, *vy, *vz;   // view direction (towards the ray origin)
+    float *wr, *wg, *wb;   // weight = throughput * (1 - transparency)
+    uint32_t *pixel;       // LOCAL pixel index inside the band
+    uint32_t *gpixel;      // GLOBAL pixel index y*W+x (jitter key)
+    uint32_t *node;
+    uint32_t *meta;        // surface index | flags << 24
+    uint32_t* count;
+    uint32_t capacity;
+};
+
+// optional float64 record of every nearest-hit query (debug / parity tests)
+struct HitDebug {
+    uint32_t *gpixel, *node;
+    int32_t* surf;
+    double *t, *P, *n;  // P, n: 3 per record
+    uint32_t* flags;
+    uint32_t* count;
+    uint32_t capacity;
+};
+
+// device counters, one block of u64
+enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_RAY, CNT_OVERFLOW_SHADE, CNT_WORK, CNT_N };
+
+struct FrameParams {
+    int32_t width, height;
+    int32_t band_rows;       // rows in this band
+    int32_t max_rec;
+    int32_t n_shadow;
+    int32_t n_surfaces, n_lights;
+    uint32_t seed_key;       // mix32(seed + GOLDEN), the per-frame part of the jitter key
+    float bg[3];
+    const int32_t* row_y;    // image row of each band row
+};
+
+// ---- jitter stream (contract: oracle/jitter.py) ----------------------------------
+__host__ __device__ inline uint32_t rt_mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x;
+}
+__host__ __device__ inline uint32_t rt_seed_key(uint32_t seed) { return rt_mix32(seed + 0x9E3779B9u); }
+__host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixel, uint32_t node, uint32_t light) {
+    uint32_t k = rt_mix32(seed_key ^ pixel);
+    k = rt_mix32(k ^ (node * 0x9E3779B1u));
+    k = rt_mix32(k ^ ((light + 1u) * 0x85EBCA6Bu));
+    return k;
+}
+__host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t s, uint32_t& u, uint32_t& v) {
+    uint32_t m = rt_mix32(key + s * 0x9E3779B9u);
+    u = m >> 8;
+    v = ((m ^ 0x68E31DA4u) * 0x2C9277B5u) >> 8;
+}
+
+// ---- launch wrappers implemented by the .hip files -------------------------------
+struct TraceArgs {
+    FrameParams fp;
+    CameraD cam;
+    const SurfD* surf;
+    const MatF* mat;
+    RayQueue in, out;
+    ShadeQueue shade;
+    HitDebug dbg;          // capacity 0 = off
+    double* accum;         // 3 per band pixel
+    unsigned long long* counters;
+    int depth;
+};
+void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
+
+struct ShadeArgs {
+    FrameParams fp;
+    const SurfF* surf;
+    const MatF* mat;
+    const LightF* light;
+    ShadeQueue q;
+    double* accum;
+    unsigned long long* counters;
+};
+void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s);
+
+void rt_launch_resolve(const double* accum, int64_t n_values, float* out_f32, uint8_t* out_u8, hipStream_t s);

@@ -1,0 +1,275 @@
+// rt_shade.hip -- Phong shading with N x N jittered soft shadows (gfx950, FP32 VALU).
+//
+// One lane per shaded hit.  For every light the lane generates the N*N sample
+// points of the light's area, and for each sample builds the shadow ray and tests
+// it against every surface IN REGISTERS -- shadow rays are never written to memory.
+// All lanes of a wave walk the same (light, sample, surface) sequence, so surface
+// and light records are wave-uniform (scalar loads / broadcasts) and the loop has
+// no divergence apart from the per-lane selects of the own-surface rule.
+//
+// Shadow rays start exactly on the hit primitive (ray_tracer.py:56).  The reference
+// relies on float64 to make the root on that primitive fall below 1e-6; FP32 cannot
+// (1e-6 is below its resolution at scene scale), so the hit primitive is resolved by
+// rule, using flags the float64 ray-tree kernel computed:
+//   plane : its own root is ~0 with either sign            -> never blocks
+//   sphere: sample leaves the surface (w.oc >= 0)          -> never blocks
+//           sample enters it: c = |P-C|^2 - r^2 > 0 in f64  -> tiny positive near root is
+//           selected and rejected => NOT blocked; else the far root t = -2 w.oc blocks
+//   box   : sample leaves through the hit face             -> never blocks
+//           sample enters: far slab exit blocks (batched path, cube.py:167-168);
+//           single-ray path: not blocked when the f64 hit point lies outside the face
+// Everything else is the ordinary test with the literal window (1e-6, distance).
+//
+// Reference: ray_tracer.py:15-85 (shadow ratio, both paths), :88-106 (intensity),
+// :129-171 (Phong), light.py:13-65 (basis + samples), surfaces/*.py intersect_batch
+// (multi-sample path) and intersect (single-ray path).
+#include "rt_device.h"
+#include "../../include/rt_amd.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+#define SHADE_BLOCK 256
+
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return F3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ f3 normalize(f3 v) {
+    float l2 = dot(v, v);
+    if (l2 == 0.f) return v;
+    return v * __frsqrt_rn(l2);
+}
+__device__ __forceinline__ float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// ---------------------------------------------------------------------------------------
+// multi-sample path: semantics of intersect_batch + mask (ray_tracer.py:70-73)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sphere_blocks_b(const SurfF& s, f3 P, f3 w, float dist, bool own, uint32_t flags) {
+    f3 oc = P - F3(s.a.x, s.a.y, s.a.z);
+    float b = dot(w, oc);                    // half of the reference's b (unit direction, a = 1)
+    float c = dot(oc, oc) - s.a.w;
+    float disc = fmaf(b, b, -c);
+    float sq = __fsqrt_rn(fmaxf(disc, 0.f));
+    float t1 = -b - sq, t2 = -b + sq;
+    float tn = t1 > 0.f ? t1 : t2;           // sphere.py:119
+    bool valid = disc >= 0.f;
+    if (own) {                               // start point lies on this sphere
+        tn = -2.f * b;
+        valid = b < 0.f && !(flags & HF_CBATCH_POS);
+    }
+    return valid && tn > RT_EPSF && tn < dist;
+}
+__device__ __forceinline__ bool plane_blocks_b(const SurfF& s, f3 P, f3 w, float dist, bool own) {
+    f3 n = F3(s.a.x, s.a.y, s.a.z);
+    float denom = dot(w, n);
+    float t = (s.a.w - dot(P, n)) / denom;   // infinite_plane.py:70-74
+    return !own && fabsf(denom) >= RT_EPSF && t > RT_EPSF && t < dist;
+}
+__device__ __forceinline__ bool box_blocks_b(const SurfF& s, f3 P, f3 w, float dist, bool own, f3 nrm) {
+    float t_near = -INFINITY, t_far = INFINITY;
+    const float oo[3] = {P.x, P.y, P.z}, dd[3] = {w.x, w.y, w.z};
+    const float lo[3] = {s.a.x, s.a.y, s.a.z}, hi[3] = {s.b.x, s.b.y, s.b.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {            // cube.py:127-153
+        if (fabsf(dd[a]) < RT_EPSF) {
+            if (oo[a] < lo[a] || oo[a] > hi[a]) t_far = -INFINITY;
+        } else {
+            float inv = 1.0f / dd[a];
+            float t1 = (lo[a] - oo[a]) * inv, t2 = (hi[a] - oo[a]) * inv;
+            t_near = fmaxf(t_near, fminf(t1, t2));
+            t_far = fminf(t_far, fmaxf(t1, t2));
+        }
+    }
+    if (own) {
+        // leaving through the hit face never blocks; entering blocks at the far slab exit
+        bool inward = dot(w, nrm) < 0.f;
+        return inward && t_far > RT_EPSF && t_far < dist;
+    }
+    if (t_near > t_far || t_far < 0.f) return false;
+    float t = t_near > RT_EPSF ? t_near : (t_far > RT_EPSF ? t_far : INFINITY);  // cube.py:167-168
+    return t > RT_EPSF && t < dist;
+}
+
+// ---------------------------------------------------------------------------------------
+// single-ray path: semantics of the scalar intersect + caller's window (ray_tracer.py:42-43)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sphere_blocks_a(const SurfF& s, f3 P, f3 w, float dist, bool own, uint32_t flags) {
+    f3 oc = P - F3(s.a.x, s.a.y, s.a.z);
+    float b = dot(w, oc);
+    float c = dot(oc, oc) - s.a.w;
+    float disc = fmaf(b, b, -c);
+    if (own) {
+        float t = -2.f * b;
+        return b < 0.f && !(flags & HF_CDOT_POS) && t > RT_EPSF && t < dist;
+    }
+    if (disc < 0.f) return false;
+    float sq = __fsqrt_rn(disc);
+    float t1 = -b - sq, t2 = -b + sq;
+    float t;
+    if (t1 > 0.f) t = t1; else if (t2 > 0.f) t = t2; else return false;  // sphere.py:54-59
+    return t > RT_EPSF && t < dist;
+}
+__device__ __forceinline__ bool plane_blocks_a(const SurfF& s, f3 P, f3 w, float dist, bool own) {
+    f3 n = F3(s.a.x, s.a.y, s.a.z);
+    float denom = dot(w, n);
+    if (own || fabsf(denom) < RT_EPSF) return false;
+    float t = (s.a.w - dot(P, n)) / denom;
+    return t > 0.f && t > RT_EPSF && t < dist;
+}
+__device__ __forceinline__ bool box_blocks_a(const SurfF& s, f3 P, f3 w, float dist, bool own, f3 nrm, uint32_t flags) {
+    float t_near = -INFINITY, t_far = INFINITY;
+    const float oo[3] = {P.x, P.y, P.z}, dd[3] = {w.x, w.y, w.z};
+    const float lo[3] = {s.a.x, s.a.y, s.a.z}, hi[3] = {s.b.x, s.b.y, s.b.z};
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {            // cube.py:45-72
+        if (fabsf(dd[a]) < RT_EPSF) {
+            if (oo[a] < lo[a] || oo[a] > hi[a]) miss = true;
+        } else {
+            float t1 = (lo[a] - oo[a]) / dd[a], t2 = (hi[a] - oo[a]) / dd[a];
+            t_near = fmaxf(t_near, fminf(t1, t2));
+            t_far = fminf(t_far, fmaxf(t1, t2));
+        }
+    }
+    if (own) {
+        bool inward = dot(w, nrm) < 0.f;
+        return inward && !miss && !(flags & HF_BOX_OUTSIDE) && t_far > RT_EPSF && t_far < dist;
+    }
+    if (miss || t_near > t_far || t_far < 0.f) return false;
+    float t = t_near > 0.f ? t_near : t_far;  // cube.py:79-86
+    return t > RT_EPSF && t < dist;
+}
+
+__device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
+
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs a) {
+    uint32_t count = *a.q.count;
+    if (count > a.q.capacity) count = a.q.capacity;
+    const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
+    const float invN = 1.0f / (float)N;
+    const float inv_n2 = 1.0f / (float)(N * N);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+
+    for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < count;
+        const uint32_t li = active ? idx : base;  // idle lanes shadow item 0 of the chunk, results dropped
+        const f3 P = F3(a.q.px[li], a.q.py[li], a.q.pz[li]);
+        const f3 nrm = F3(a.q.nx[li], a.q.ny[li], a.q.nz[li]);
+        const f3 view = F3(a.q.vx[li], a.q.vy[li], a.q.vz[li]);
+        const uint32_t gpix = a.q.gpixel[li], node = a.q.node[li], meta = a.q.meta[li];
+        const int own_id = (meta >> 24) & HF_NO_OWN ? -1 : (int)(meta & 0xFFFFFFu);
+        const uint32_t flags = meta >> 24;
+        const MatF m = a.mat[a.surf[meta & 0xFFFFFFu].mat];
+
+        f3 color = F3(0.f, 0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const LightF lt = a.light[l];
+            const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+            const float lc2 = dot(lrel, lrel);
+            const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
+            const f3 ldir = lrel * linv;
+            float ratio;
+            if (lt.point_path) {
+                // ---- one ray to the light centre (ray_tracer.py:36-48)
+                const float dist = lc2 * linv;
+                float f = 1.f;
+                for (int s = 0; s < S; ++s) {
+                    const SurfF sf = a.surf[s];
+                    const bool own = s == own_id;
+                    bool blk;
+                    if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
+                    else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
+                    else blk = box_blocks_a(sf, P, ldir, dist, own, nrm, flags);
+                    f = blk ? f * sf.transp : f;
+                }
+                ratio = f;
+            } else {
+                // ---- light basis (light.py:24-30) and the N x N grid (light.py:51-63)
+                const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
+                const f3 right = normalize(cross(ldir, perp));
+                const f3 up = normalize(cross(right, ldir));
+                const uint32_t key = rt_grid_key(a.fp.seed_key, gpix, node, (uint32_t)l);
+                float sum = 0.f;
+                uint32_t s_idx = 0;
+                for (int i = 0; i < N; ++i) {
+                    for (int j = 0; j < N; ++j, ++s_idx) {
+                        uint32_t ub, vb;
+                        rt_sample_bits(key, s_idx, ub, vb);
+                        const float u = ((float)i + (float)ub * 5.9604644775390625e-08f) * invN - 0.5f;
+                        const float v = ((float)j + (float)vb * 5.9604644775390625e-08f) * invN - 0.5f;
+                        const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
+                        const float d2 = dot(sv, sv);
+                        const float dinv = __frsqrt_rn(d2);
+                        const f3 w = sv * dinv;
+                        const float dist = d2 * dinv;
+                        float f = 1.f;
+                        for (int s = 0; s < S; ++s) {
+                            const SurfF sf = a.surf[s];
+                            const bool own = s == own_id;
+                            bool blk;
+                            if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_b(sf, P, w, dist, own, flags);
+                            else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_b(sf, P, w, dist, own);
+                            else blk = box_blocks_b(sf, P, w, dist, own, nrm);
+                            f = blk ? f * sf.transp : f;
+                        }
+                        sum += f;
+                    }
+                }
+                ratio = sum * inv_n2;
+            }
+            // ---- intensity (ray_tracer.py:105) and Phong terms (:157-170)
+            const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
+            if (inten != 0.f) {
+                const float ndl = fmaxf(0.f, dot(nrm, ldir));
+                const float k2 = 2.f * dot(ldir, nrm);
+                const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
+                const float rv = dot(rdir, view);
+                const float sp = rv > 0.f ? powf(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+                const float spi = sp * lt.spec;
+                color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
+                color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
+                color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
+            }
+        }
+        if (active) {
+            const uint32_t lp = a.q.pixel[idx];
+            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+        }
+    }
+}
+
+void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_BLOCK), 0, s, a);
+}
+
+// ---------------------------------------------------------------------------------------
+// resolve: clip(colour, 0, 1) * 255 (ray_tracer.py:330-331) -> float32 image and its
+// uint8 truncation (np.uint8, ray_tracer.py:438)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ accum, int64_t n, float* out_f32, uint8_t* out_u8) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        double c = accum[i];
+        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+        float v = (float)(c * 255.0);
+        if (out_f32) out_f32[i] = v;
+        if (out_u8) out_u8[i] = (uint8_t)v;  // same value np.uint8() gives for the float image
+    }
+}
+
+void rt_launch_resolve(const double* accum, int64_t n_values, float* out_f32, uint8_t* out_u8, hipStream_t s) {
+    int64_t blocks = (n_values + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, accum, n_values, out_f32, out_u8);
+}
