@@ -99,6 +99,8 @@ typedef struct rt_render_params {
 } rt_render_params;
 
 #define RT_FLAG_NONE 0u
+#define RT_FLAG_GENERAL_SHADE 1u /* force the any-scene-size shading kernel (cross-check of the
+                                    register-resident small-scene kernel)                  */
 
 /* Counters use the definitions both sides of the comparison share:
  * primary = pixels; secondary = reflection/transparency rays actually intersected

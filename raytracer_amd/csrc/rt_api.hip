@@ -57,6 +57,7 @@ struct rt_handle {
     SurfF* d_surff = nullptr;
     MatF* d_mat = nullptr;
     LightF* d_light = nullptr;
+    int has_box = 0, all_opaque = 1;
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
 
@@ -191,6 +192,8 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         ShadeArgs sa{};
         sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq;
         sa.accum = h->d_accum; sa.counters = h->d_counters;
+        sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
+        sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], st));
@@ -407,6 +410,9 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     for (int c = 0; c < 3; ++c) h->bg[c] = (float)d->background[c];
     h->cam = cam;
     h->shadow_rays_per_hit = rays_per_hit;
+    h->has_box = any_box ? 1 : 0;
+    h->all_opaque = 1;
+    for (int s = 0; s < S; ++s) if (sf[s].transp != 0.f) h->all_opaque = 0;
     // algorithmic FP32 flop per shaded hit: per shadow ray the surface tests + 26 for building the
     // ray; per (hit, light) 30 for the sampling basis + 52 for the Phong terms; 12 for the blend
     h->flop_per_hit = rays_per_hit * (test_flops + 26.0) + L * 82.0 + 12.0;

@@ -135,8 +135,12 @@ struct TraceArgs {
 };
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
 
+enum { SHADE_AUTO = 0, SHADE_GENERAL = 1 };
 struct ShadeArgs {
     FrameParams fp;
+    int32_t variant;     // SHADE_AUTO picks the register-resident kernel for small scenes
+    int32_t has_box;     // scene contains at least one box
+    int32_t all_opaque;  // every surface's material has transparency == 0
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;

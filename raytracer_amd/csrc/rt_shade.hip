@@ -146,7 +146,7 @@ __device__ __forceinline__ bool box_blocks_a(const SurfF& s, f3 P, f3 w, float d
 
 __device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs a) {
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     uint32_t count = *a.q.count;
     if (count > a.q.capacity) count = a.q.capacity;
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -247,8 +247,234 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade(ShadeArgs a) {
     }
 }
 
+
+// =======================================================================================
+// Small scenes (<= SMALL_MAX surfaces): everything that depends only on (hit, surface)
+// is hoisted out of the light / sample loops into registers:
+//   sphere j : oc = P - C_j and cn = -(|oc|^2 - r^2)
+//   plane  j : h  = offset - P.n_j
+//   box    j : lo - P, hi - P
+// so one (sample, sphere) test is: 3 FMA (w.oc), 1 FMA (disc), sqrt, 1 bit-select, 1 sub,
+// 2 compares.  The root choice `t1 if t1 > 0 else t2` (sphere.py:119) depends only on
+// sign(c): both roots have the sign pattern of c, so the sign bit of cn picks the root.
+// The hit's own surface is made inert in the uniform loop (cn = -inf, h = NaN, box
+// moved to +1e30) and resolved by the per-lane own-surface rule afterwards.
+// =======================================================================================
+#define SMALL_MAX 8
+
+template <bool HAS_BOX, bool ALL_OPAQUE>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_small(ShadeArgs a) {
+    uint32_t count = *a.q.count;
+    if (count > a.q.capacity) count = a.q.capacity;
+    const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
+    const float invN = 1.0f / (float)N;
+    const float inv_n2 = 1.0f / (float)(N * N);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+
+    // wave-uniform scene constants: 4 type bits per surface in one word; transparencies only
+    // where a surface can attenuate instead of block
+    uint32_t tword = 0;
+    float str[SMALL_MAX];
+#pragma unroll
+    for (int j = 0; j < SMALL_MAX; ++j) {
+        str[j] = 0.f;
+        uint32_t ty = 0xFu;
+        if (j < S) { ty = (uint32_t)a.surf[j].type; if (!ALL_OPAQUE) str[j] = a.surf[j].transp; }
+        tword |= ty << (4 * j);
+    }
+    tword = __builtin_amdgcn_readfirstlane(tword);
+#define STYPE(j) ((tword >> (4 * (j))) & 0xFu)
+
+    for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
+        const uint32_t idx = base + lane;
+        const bool active = idx < count;
+        const uint32_t li = active ? idx : base;
+        const f3 P = F3(a.q.px[li], a.q.py[li], a.q.pz[li]);
+        const f3 nrm = F3(a.q.nx[li], a.q.ny[li], a.q.nz[li]);
+        const f3 view = F3(a.q.vx[li], a.q.vy[li], a.q.vz[li]);
+        const uint32_t gpix = a.q.gpixel[li], node = a.q.node[li], meta = a.q.meta[li];
+        const uint32_t flags = meta >> 24;
+        const int own_id = (flags & HF_NO_OWN) ? -1 : (int)(meta & 0xFFFFFFu);
+        const SurfF own_sf = a.surf[meta & 0xFFFFFFu];
+        const MatF m = a.mat[own_sf.mat];
+
+        // ---- per-(hit, surface) constants
+        float g[SMALL_MAX][HAS_BOX ? 6 : 4];
+#pragma unroll
+        for (int j = 0; j < SMALL_MAX; ++j) {
+#pragma unroll
+            for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
+            if (j < S) {
+                const SurfF sf = a.surf[j];
+                const bool own = j == own_id;
+                if (STYPE(j) == RT_SURF_SPHERE) {
+                    const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
+                    g[j][0] = oc.x; g[j][1] = oc.y; g[j][2] = oc.z;
+                    g[j][3] = own ? -INFINITY : 0.f - (dot(oc, oc) - sf.a.w);
+                } else if (STYPE(j) == RT_SURF_PLANE) {
+                    g[j][0] = sf.a.x; g[j][1] = sf.a.y; g[j][2] = sf.a.z;
+                    g[j][3] = own ? NAN : sf.a.w - dot(P, F3(sf.a.x, sf.a.y, sf.a.z));
+                } else if (HAS_BOX) {
+                    g[j][0] = own ? 1e30f : sf.a.x - P.x; g[j][1] = own ? 1e30f : sf.a.y - P.y; g[j][2] = own ? 1e30f : sf.a.z - P.z;
+                    g[j][3] = own ? 1e30f : sf.b.x - P.x; g[j][4] = own ? 1e30f : sf.b.y - P.y; g[j][5] = own ? 1e30f : sf.b.z - P.z;
+                }
+            }
+        }
+        // ---- own-surface rule operands (per lane)
+        const bool own_sphere = own_id >= 0 && own_sf.type == RT_SURF_SPHERE;
+        const bool own_box = HAS_BOX && own_id >= 0 && own_sf.type == RT_SURF_BOX;
+        // sphere: oc; box: outward normal.  w . ov < 0  <=>  the sample enters the body
+        const f3 ov = own_sphere ? P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z) : nrm;
+        const bool own_sph_blocks_b = own_sphere && !(flags & HF_CBATCH_POS);
+        const bool own_sph_blocks_a = own_sphere && !(flags & HF_CDOT_POS);
+        const float own_tr = own_sf.transp;
+        float ob[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ob[c] = 0.f;
+        if (HAS_BOX && own_box) {
+            ob[0] = own_sf.a.x - P.x; ob[1] = own_sf.a.y - P.y; ob[2] = own_sf.a.z - P.z;
+            ob[3] = own_sf.b.x - P.x; ob[4] = own_sf.b.y - P.y; ob[5] = own_sf.b.z - P.z;
+        }
+
+        f3 color = F3(0.f, 0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const LightF lt = a.light[l];
+            const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+            const float lc2 = dot(lrel, lrel);
+            const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
+            const f3 ldir = lrel * linv;
+            float ratio;
+            if (lt.point_path) {
+                // ---- one ray to the light centre (ray_tracer.py:36-48); rare path, literal form
+                const float dist = lc2 * linv;
+                float f = 1.f;
+                for (int s = 0; s < S; ++s) {
+                    const SurfF sf = a.surf[s];
+                    const bool own = s == own_id;
+                    bool blk;
+                    if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
+                    else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
+                    else blk = box_blocks_a(sf, P, ldir, dist, own, nrm, flags);
+                    f = blk ? f * sf.transp : f;
+                }
+                ratio = f;
+            } else {
+                const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
+                const f3 right = normalize(cross(ldir, perp));
+                const f3 up = normalize(cross(right, ldir));
+                const uint32_t key = rt_grid_key(a.fp.seed_key, gpix, node, (uint32_t)l);
+                const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
+                float sum = 0.f;
+                uint32_t ctr = key;
+                for (int i = 0; i < N; ++i) {
+                    const float cu = ((float)i * invN - 0.5f) * lt.radius;
+                    for (int j = 0; j < N; ++j) {
+                        uint32_t ub, vb;
+                        rt_sample_bits(ctr, 0u, ub, vb);
+                        ctr += 0x9E3779B9u;
+                        const float cv = ((float)j * invN - 0.5f) * lt.radius;
+                        const float ur = fmaf((float)ub, ku, cu);
+                        const float vr = fmaf((float)vb, ku, cv);
+                        const f3 sv = F3(fmaf(up.x, vr, fmaf(right.x, ur, lrel.x)), fmaf(up.y, vr, fmaf(right.y, ur, lrel.y)),
+                                         fmaf(up.z, vr, fmaf(right.z, ur, lrel.z)));
+                        const float d2 = dot(sv, sv);
+                        const float dinv = __builtin_amdgcn_rsqf(d2);
+                        const f3 w = sv * dinv;
+                        const float dist = d2 * dinv;
+                        float iw[3] = {0.f, 0.f, 0.f};
+                        if (HAS_BOX) {
+                            // |w_a| < 1e-6 is "parallel" (cube.py:129); clamping the magnitude keeps the slab logic
+                            // branch-free: inside the slab both plane distances become huge with opposite signs
+                            iw[0] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.x), RT_EPSF), w.x));
+                            iw[1] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.y), RT_EPSF), w.y));
+                            iw[2] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.z), RT_EPSF), w.z));
+                        }
+                        bool any = false;
+                        float f = 1.f;
+#pragma unroll
+                        for (int s = 0; s < SMALL_MAX; ++s) {
+                            if (s < S) {
+                                bool blk;
+                                if (STYPE(s) == RT_SURF_SPHERE) {
+                                    const float b = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
+                                    const float disc = fmaf(b, b, g[s][3]);
+                                    const float sq = __builtin_amdgcn_sqrtf(disc);  // NaN when the ray misses
+                                    const float ssq = copysignf(sq, g[s][3]);       // outside: near root, inside: far root
+                                    const float tn = ssq - b;
+                                    blk = tn > RT_EPSF && tn < dist;
+                                } else if (STYPE(s) == RT_SURF_PLANE) {
+                                    const float denom = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
+                                    const float t = g[s][3] * __builtin_amdgcn_rcpf(denom);
+                                    blk = fabsf(denom) >= RT_EPSF && t > RT_EPSF && t < dist;
+                                } else if (HAS_BOX) {
+                                    const float t1x = g[s][0] * iw[0], t2x = g[s][3] * iw[0];
+                                    const float t1y = g[s][1] * iw[1], t2y = g[s][4] * iw[1];
+                                    const float t1z = g[s][2] * iw[2], t2z = g[s][5] * iw[2];
+                                    const float tnear = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                                    const float tfar = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                                    const float t = tnear > RT_EPSF ? tnear : tfar;   // cube.py:167-168
+                                    blk = tnear <= tfar && t > RT_EPSF && t < dist;
+                                } else blk = false;
+                                if (ALL_OPAQUE) any = any || blk;
+                                else f = blk ? f * str[s] : f;
+                            }
+                        }
+                        // ---- the hit's own surface, by rule (see the header of this file)
+                        {
+                            const float bo = fmaf(w.z, ov.z, fmaf(w.y, ov.y, w.x * ov.x));
+                            const float t2 = -2.f * bo;
+                            bool blk = own_sph_blocks_b && bo < 0.f && t2 > RT_EPSF && t2 < dist;
+                            if (HAS_BOX) {
+                                const float t2x = fmaxf(ob[0] * iw[0], ob[3] * iw[0]);
+                                const float t2y = fmaxf(ob[1] * iw[1], ob[4] * iw[1]);
+                                const float t2z = fmaxf(ob[2] * iw[2], ob[5] * iw[2]);
+                                const float tfar = fminf(fminf(t2x, t2y), t2z);
+                                blk = blk || (own_box && bo < 0.f && tfar > RT_EPSF && tfar < dist);
+                            }
+                            if (ALL_OPAQUE) any = any || blk;
+                            else f = blk ? f * own_tr : f;
+                        }
+                        if (ALL_OPAQUE) sum += any ? 0.f : 1.f;
+                        else sum += f;
+                    }
+                }
+                ratio = sum * inv_n2;
+            }
+            const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
+            if (inten != 0.f) {
+                const float ndl = fmaxf(0.f, dot(nrm, ldir));
+                const float k2 = 2.f * dot(ldir, nrm);
+                const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
+                const float rv = dot(rdir, view);
+                const float sp = rv > 0.f ? powf(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+                const float spi = sp * lt.spec;
+                color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
+                color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
+                color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
+            }
+        }
+        if (active) {
+            const uint32_t lp = a.q.pixel[idx];
+            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+        }
+    }
+}
+
 void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
-    hipLaunchKernelGGL(k_shade, dim3(blocks), dim3(SHADE_BLOCK), 0, s, a);
+    const dim3 g(blocks), b(SHADE_BLOCK);
+    if (a.variant == SHADE_GENERAL || a.fp.n_surfaces > SMALL_MAX) {
+        hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
+    } else if (a.has_box) {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_small<true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_small<true, false>), g, b, 0, s, a);
+    } else {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_small<false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_small<false, false>), g, b, 0, s, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
