@@ -535,7 +535,7 @@ double rto_intersect_batch(int type, const double* p, const double* o, const dou
     ds.surf_material = &mt; ds.mat_param = mat; ds.cam_look_at[2] = -1; ds.cam_up[1] = 1;
     scene_t sc; if (build_scene(&ds, &sc) != 0) { free_scene(&sc); return NAN; }
     v3 O = V(o[0], o[1], o[2]), D = V(d[0], d[1], d[2]); double t;
-    switch (type) {
+    switch (sc.surf[0].type) {
         case RT_SURF_SPHERE: t = sphere_batch(&sc.surf[0], O, D); break;
         case RT_SURF_PLANE: t = plane_batch(&sc.surf[0], O, D); break;
         default: t = box_batch(&sc.surf[0], O, D); break;

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs the reference tree (build container only)")
+
+
+def _gpu_available():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/rt_oracle.c), compiled on demand with gcc."""
+    from oracle import rt_oracle
+    rt_oracle.build()
+    rt_oracle.lib()
+    return rt_oracle
+
+
+@pytest.fixture(scope="session")
+def renderer():
+    """One GPU context for the whole session; the product path has no CPU fallback."""
+    if not _gpu_available():
+        pytest.skip("no GPU visible")
+    from raytracer_amd import runtime
+    r = runtime.Renderer(0)
+    yield r
+    r.close()
