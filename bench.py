@@ -111,10 +111,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     rays = 0
+    wave_light = [0] * 8
     ms_shade = flop_shade = ms_trace = ms_resolve = 0.0
     for i in range(args.steps):
         _, st = dr.render(seed=1000 + i)
         rays += st["total_rays"]
+        wave_light = [x + y for x, y in zip(wave_light, st["wave_light"])]
         ms_shade += st["ms_shade"]; flop_shade += st["flop_shade"]; ms_trace += st["ms_trace"]; ms_resolve += st["ms_resolve"]
     barrier()
     dt = time.perf_counter() - t0
@@ -152,6 +154,7 @@ def main():
                        else f"scenes/{scene_name}.txt at {W}x{H}",
                        "rays_per_frame": rays_total / steps, "partition": f"row stripes x{world}, uint8 gather to rank 0",
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},
+            "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "-"], wave_light)),
             "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "resolve": ms_resolve / steps},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,

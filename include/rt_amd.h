@@ -101,6 +101,8 @@ typedef struct rt_render_params {
 #define RT_FLAG_NONE 0u
 #define RT_FLAG_GENERAL_SHADE 1u /* force the any-scene-size shading kernel (cross-check of the
                                     register-resident small-scene kernel)                  */
+#define RT_FLAG_NO_CULL 2u       /* evaluate every shadow ray against every surface: no per-
+                                    (hit, light) classification of surfaces (A/B measurements) */
 
 /* Counters use the definitions both sides of the comparison share:
  * primary = pixels; secondary = reflection/transparency rays actually intersected
@@ -122,6 +124,11 @@ typedef struct rt_stats {
     double ms_shade;          /* shading + soft-shadow kernel (the dominant one)     */
     double ms_resolve;        /* accumulate -> clip*255 -> f32/u8                    */
     double flop_shade;        /* algorithmic FP32 flop of the shade kernel launches  */
+    uint64_t wave_light[8];   /* how the shading kernel resolved each (wavefront, light):
+                                 [0] no surface in reach, ratio = 1 without sampling;
+                                 [1..4] compact loop with 1..4 linear tests per sample;
+                                 [5] generic loop (every ray against every surface);
+                                 [6] single-ray path (N == 1 or shadow_intensity == 0)   */
 } rt_stats;
 
 typedef struct rt_handle rt_handle;

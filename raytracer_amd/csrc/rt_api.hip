@@ -69,7 +69,9 @@ struct rt_handle {
     HitDebug dbg{};
     double* d_accum = nullptr;
     unsigned long long* d_counters = nullptr;
-    uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug
+    uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
+    uint2* d_deferred = nullptr;
+    int arena_lights = 0;
     int32_t* d_row_y = nullptr;
     size_t row_y_cap = 0;
     float* d_out_f32 = nullptr;
@@ -97,11 +99,14 @@ void free_frame_buffers(rt_handle* h) {
     if (h->arena) (void)hipFree(h->arena);
     h->arena = nullptr;
     h->band_capacity = 0;
+    h->arena_lights = 0;
 }
 
 // carve the SoA queues out of one arena
 int ensure_band_capacity(rt_handle* h, size_t pixels) {
-    if (pixels <= h->band_capacity) return RT_OK;
+    const int lights = h->L > 0 ? h->L : 1;
+    if (pixels <= h->band_capacity && lights <= h->arena_lights) return RT_OK;
+    if (pixels < h->band_capacity) pixels = h->band_capacity;
     free_frame_buffers(h);
     const size_t rcap = pixels * kRayFactor, scap = pixels * kShadeFactor;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -109,6 +114,8 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     bytes += 2 * (6 * al(rcap * 8) + 5 * al(rcap * 4));  // two ray queues
     bytes += 16 * al(scap * 4);                         // shade queue
     bytes += al(pixels * 3 * 8);                        // accumulators
+    const size_t dcap = (scap / 64 + 1) * (size_t)lights; // every (64-hit chunk, light) pair at most once
+    bytes += al(dcap * sizeof(uint2));
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, bytes);
     if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes for frame queues failed");
@@ -132,7 +139,9 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     s.count = h->d_qcounts + 2;
     s.capacity = (uint32_t)scap;
     h->d_accum = (double*)take(pixels * 3 * 8);
+    h->d_deferred = (uint2*)take(dcap * sizeof(uint2));
     h->band_capacity = pixels;
+    h->arena_lights = lights;
     return RT_OK;
 }
 
@@ -161,7 +170,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     const size_t pixels = (size_t)n_rows * p->width;
     HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N, st));
-    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * 4, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * 8, st));
     HIP_TRY(h, hipMemsetAsync(h->d_accum, 0, sizeof(double) * 3 * pixels, st));
 
     FrameParams fp{};
@@ -194,6 +203,9 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.accum = h->d_accum; sa.counters = h->d_counters;
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
+        sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
+        sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
+        sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], st));
@@ -247,6 +259,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
         s.primary_rays += br.c[CNT_PRIMARY]; s.secondary_rays += br.c[CNT_SECONDARY];
         s.depth_cut += br.c[CNT_DEPTH_CUT]; s.shaded_points += br.c[CNT_SHADED];
         s.ms_trace += br.ms_trace; s.ms_shade += br.ms_shade; s.ms_resolve += br.ms_resolve;
+        for (int k = 0; k < 7; ++k) s.wave_light[k] += br.c[CNT_WL_NONE + k];
         s.bands += 1;
         r0 += n;
     }
@@ -277,7 +290,7 @@ int rt_create(int device, rt_handle** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess &&
-              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * 4) == hipSuccess;
+              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * 8) == hipSuccess;
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) { rt_destroy(h); return RT_ERR_DEVICE; }
     *out = h;
@@ -347,6 +360,7 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
             a.d[4] = p3 * p3;            // sphere.py:38
             a.d[5] = std::pow(p3, 2.0);  // sphere.py:93 (Python float ** 2)
             f.a = make_float4((float)p.x, (float)p.y, (float)p.z, (float)(p3 * p3));
+            f.c = make_float4((float)p3, 0.f, 0.f, 0.f);
             test_flops += 20;
         } else if (type == RT_SURF_PLANE || type == RT_SURF_PLANE_RAW) {
             if (type == RT_SURF_PLANE_RAW) p = divs(p, std::sqrt(dotb(p, p)));  // infinite_plane.py:8
@@ -361,6 +375,7 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
             a.d[3] = p.x + half; a.d[4] = p.y + half; a.d[5] = p.z + half;
             f.a = make_float4((float)a.d[0], (float)a.d[1], (float)a.d[2], 0.f);
             f.b = make_float4((float)a.d[3], (float)a.d[4], (float)a.d[5], 0.f);
+            f.c = make_float4((float)p.x, (float)p.y, (float)p.z, (float)(std::fabs(p3) * 0.8660254037844386 * 1.00001));
             test_flops += 24; any_box = true;
         } else {
             return fail(h, RT_ERR_INVALID, "surface " + std::to_string(s) + ": unknown type");

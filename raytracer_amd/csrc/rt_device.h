@@ -23,9 +23,10 @@ struct SurfD {
 //   sphere: a = (cx, cy, cz, r*r)
 //   plane : a = (nx, ny, nz, offset)
 //   box   : a = (minx, miny, minz, -), b = (maxx, maxy, maxz, -)
-struct SurfF {
+struct __attribute__((aligned(16))) SurfF {
     float4 a;
     float4 b;       // box only
+    float4 c;       // sphere: (radius, -, -, -); box: bounding sphere (centre, radius)
     int32_t type;
     float transp;   // transparency of the surface's material (shadow attenuation)
     int32_t mat;
@@ -90,7 +91,10 @@ struct HitDebug {
 };
 
 // device counters, one block of u64
-enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_RAY, CNT_OVERFLOW_SHADE, CNT_WORK, CNT_N };
+enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_RAY, CNT_OVERFLOW_SHADE, CNT_WORK,
+       // how the shading kernel resolved each (wave, light): ratio = 1 without sampling, compact loop
+       // with 1..4 linear tests, generic loop (some lane needs it / more than 4 candidates), single-ray path
+       CNT_WL_NONE, CNT_WL_K1, CNT_WL_K2, CNT_WL_K3, CNT_WL_K4, CNT_WL_GENERIC, CNT_WL_POINT, CNT_N };
 
 struct FrameParams {
     int32_t width, height;
@@ -141,6 +145,11 @@ struct ShadeArgs {
     int32_t variant;     // SHADE_AUTO picks the register-resident kernel for small scenes
     int32_t has_box;     // scene contains at least one box
     int32_t all_opaque;  // every surface's material has transparency == 0
+    int32_t no_cull;     // 1: always run the generic per-sample loop (no per-light classification)
+    uint32_t* work;      // shared work counter of the fast kernel (zeroed per band)
+    uint32_t* work2;     // shared work counter of the deferred kernel
+    uint2* deferred;     // (first hit of a 64-hit chunk, light) pairs left to the generic loop
+    uint32_t* deferred_count;
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;

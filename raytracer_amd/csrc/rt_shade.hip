@@ -249,32 +249,329 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 
 
 // =======================================================================================
-// Small scenes (<= SMALL_MAX surfaces): everything that depends only on (hit, surface)
-// is hoisted out of the light / sample loops into registers:
-//   sphere j : oc = P - C_j and cn = -(|oc|^2 - r^2)
-//   plane  j : h  = offset - P.n_j
-//   box    j : lo - P, hi - P
-// so one (sample, sphere) test is: 3 FMA (w.oc), 1 FMA (disc), sqrt, 1 bit-select, 1 sub,
-// 2 compares.  The root choice `t1 if t1 > 0 else t2` (sphere.py:119) depends only on
-// sign(c): both roots have the sign pattern of c, so the sign bit of cn picks the root.
-// The hit's own surface is made inert in the uniform loop (cn = -inf, h = NaN, box
-// moved to +1e30) and resolved by the per-lane own-surface rule afterwards.
+// Small scenes (<= SMALL_MAX surfaces): two kernels.
+//
+// k_shade_fast      classifies, per (hit, light), every surface against the light's sample
+//                   square (all samples lie within rho = radius/sqrt(2) of the light centre L):
+//       NEVER   : the surface cannot touch any segment P->sample (distance from the segment
+//                 P->L to the sphere centre exceeds r + rho; all samples on P's side of a
+//                 plane; a box's bounding sphere out of reach) -> no test at all
+//       LINEAR  : P outside the sphere and every sample farther away than the tangent
+//                 length sqrt(c): "segment hits sphere" == "direction inside the tangent
+//                 cone" == sv.(-oc/sqrt(c)) >= |sv|.  With sv = lrel + ur*right + vr*up that
+//                 is  A + ur*B + vr*C >= len  with A,B,C fixed per (hit, light, sphere) and
+//                 len = sqrt(|lrel|^2 + ur^2 + vr^2) (right, up are orthogonal to lrel).
+//                 Planes: segment crosses the plane  <=>  A + ur*B + vr*C > 0.
+//                 The hit's own sphere: sample enters it  <=>  same form with -oc.
+//                 => 3 FMA per (sample, surface); no shadow ray is ever built.
+//       GENERAL : touching / containing geometry, light nearer than the surface, boxes in
+//                 reach, single-ray lights.
+//     The decision is taken per wavefront (ballot).  A wave whose lanes need no surface for a
+//     light gets ratio = 1 without generating a sample; otherwise the surfaces some lane needs
+//     (at most KMAX) are compacted into registers and the sample loop runs only those.  A
+//     (wave, light) pair with a GENERAL lane, or more than KMAX candidates, is appended to a
+//     deferred list.  Margins (2e-4 relative) keep NEVER / LINEAR strictly inside the region
+//     where they agree with the generic test.
+//
+// k_shade_deferred  processes the deferred (64-hit chunk, light) pairs with the generic loop:
+//     every shadow ray is built and tested against every surface, with everything that
+//     depends only on (hit, surface) hoisted into registers (sphere: oc and -(|oc|^2 - r^2);
+//     plane: normal and offset - P.n; box: corners - P).  One (sample, sphere) test is 3 FMA
+//     (w.oc) + FMA (disc) + sqrt + bit-select + sub + 2 compares: the root choice
+//     `t1 if t1 > 0 else t2` (sphere.py:119) depends only on sign(c), so the sign bit of -c
+//     picks the root.  The hit's own surface is inert in that loop (c = +inf, h = NaN, box at
+//     +1e30) and resolved by the own-surface rule.
+//
+// Light contributions are additive, so the two kernels simply add into the same pixel
+// accumulators.
 // =======================================================================================
 #define SMALL_MAX 8
+#define NSLOT (SMALL_MAX + 1)  // + one slot for the hit's own sphere
+#define KMAX 8                 // linear tests the compact sample loop keeps in registers
 
-template <bool HAS_BOX, bool ALL_OPAQUE>
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_small(ShadeArgs a) {
+struct HitRec {
+    f3 P, nrm, view;
+    uint32_t gpix, node, flags;
+    int own_id;
+};
+
+__device__ __forceinline__ HitRec load_hit(const ShadeQueue& q, uint32_t li) {
+    HitRec h;
+    h.P = F3(q.px[li], q.py[li], q.pz[li]);
+    h.nrm = F3(q.nx[li], q.ny[li], q.nz[li]);
+    h.view = F3(q.vx[li], q.vy[li], q.vz[li]);
+    h.gpix = q.gpixel[li]; h.node = q.node[li];
+    const uint32_t meta = q.meta[li];
+    h.flags = meta >> 24;
+    h.own_id = (int)(meta & 0xFFFFFFu);
+    return h;
+}
+
+// intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light
+__device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio) {
+    const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
+    if (inten != 0.f) {
+        const float ndl = fmaxf(0.f, dot(nrm, ldir));
+        const float k2 = 2.f * dot(ldir, nrm);
+        const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
+        const float rv = dot(rdir, view);
+        const float sp = rv > 0.f ? powf(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+        const float spi = sp * lt.spec;
+        color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
+        color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
+        color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
+    }
+}
+
+// N x N jittered samples of one light against K compacted linear tests.  Entry e blocks the
+// sample iff  A + ur*B + vr*C - len*tm >= 0  (tm = 1: tangent cone of a sphere, tm = 0: plane
+// crossing); tm / tr are wave-uniform.  All-opaque scenes only need "any entry blocks" =
+// sign of the maximum, shifted into a bit mask and counted once per row.
+// Returns the sum of the light factors of the N*N samples.
+template <int K, bool ALL_OPAQUE>
+__device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
+                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tm)[KMAX],
+                                                 const float (&tr)[KMAX]) {
+    float sum = 0.f;
+    uint32_t open_samples = 0;
+    uint32_t ctr = key;
+    for (int i = 0; i < N; ++i) {
+        for (int j0 = 0; j0 < N; j0 += 32) {
+            const int j1 = j0 + 32 < N ? j0 + 32 : N;
+            uint32_t mask = 0;
+            for (int j = j0; j < j1; ++j) {
+                const uint32_t mm = rt_mix32(ctr);
+                ctr += 0x9E3779B9u;
+                const uint32_t mv = (mm ^ 0x68E31DA4u) * 0x2C9277B5u;
+                // (i << 24) | (m >> 8): the cell index rides in the top byte of the 24-bit jitter
+                const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 8), ku, koff);
+                const float vr = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)j, mv, 8), ku, koff);
+                const float len = __builtin_amdgcn_sqrtf(fmaf(ur, ur, fmaf(vr, vr, lc2)));
+                float val[K];
+#pragma unroll
+                for (int e = 0; e < K; ++e) val[e] = fmaf(-len, tm[e], fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e])));
+                if (ALL_OPAQUE) {
+                    float vmax = val[0];
+#pragma unroll
+                    for (int e = 1; e < K; ++e) vmax = __builtin_fmaxf(vmax, val[e]);
+                    // sign bit set <=> no entry blocks this sample
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(vmax), 31);
+                } else {
+                    float f = 1.f;
+#pragma unroll
+                    for (int e = 0; e < K; ++e) f = val[e] >= 0.f ? f * tr[e] : f;
+                    sum += f;
+                }
+            }
+            if (ALL_OPAQUE) open_samples += (uint32_t)__popc(mask);
+        }
+    }
+    return ALL_OPAQUE ? (float)open_samples : sum;
+}
+
+template <bool ALL_OPAQUE>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
     uint32_t count = *a.q.count;
     if (count > a.q.capacity) count = a.q.capacity;
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    const bool classify = !a.no_cull && N < 256;
 
-    // wave-uniform scene constants: 4 type bits per surface in one word; transparencies only
-    // where a surface can attenuate instead of block
+    // wave-uniform: 4 type bits per surface in one word
+    uint32_t tword = 0;
+#pragma unroll
+    for (int j = 0; j < SMALL_MAX; ++j) tword |= (j < S ? (uint32_t)a.surf[j].type : 0xFu) << (4 * j);
+    tword = __builtin_amdgcn_readfirstlane(tword);
+#define STYPE(j) ((tword >> (4 * (j))) & 0xFu)
+
+    // waves pull 64 hits at a time from a shared counter: classification makes the cost per hit uneven
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.work, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= count) break;
+        const uint32_t idx = base + lane;
+        const bool active = idx < count;
+        const HitRec h = load_hit(a.q, active ? idx : base);  // idle lanes shadow the chunk's first hit, results dropped
+        const f3 P = h.P;
+        const SurfF own_sf = a.surf[h.own_id];
+        const MatF m = a.mat[own_sf.mat];
+        const bool own_valid = !(h.flags & HF_NO_OWN);
+        const bool own_sphere = own_valid && own_sf.type == RT_SURF_SPHERE;
+        const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);  // own sphere: oc
+        const bool own_sph_blocks = own_sphere && !(h.flags & HF_CBATCH_POS);
+
+        f3 color = F3(0.f, 0.f, 0.f);
+        for (int l = 0; l < L; ++l) {
+            const LightF lt = a.light[l];
+            bool defer = lt.point_path || !classify;
+            float ratio = 1.f;
+            const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+            const float lc2 = dot(lrel, lrel);
+            const float linv = lc2 > 0.f ? __builtin_amdgcn_rsqf(lc2) : 0.f;
+            const f3 ldir = lrel * linv;
+            if (!defer) {
+                const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);  // light.py:24-27
+                const f3 right = normalize(cross(ldir, perp));
+                const f3 up = normalize(cross(right, ldir));
+                const float llen = lc2 * linv;
+                const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f;
+                const float inv_lc2 = linv * linv;
+                const float s_hi_scale = llen > 1.5f * rho ? 1.0002f / (llen - rho) : 1e30f;
+                // a light whose Phong terms vanish for this hit (back-facing and no specular lobe
+                // towards the viewer) contributes exactly 0 whatever its shadow ratio: no surface
+                // is relevant for such a lane
+                const float ndl0 = dot(h.nrm, ldir);
+                const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
+                const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
+                float A[NSLOT], B[NSLOT], C[NSLOT];
+                bool gen = false;
+                uint32_t lin = 0;
+#pragma unroll
+                for (int j = 0; j < SMALL_MAX; ++j) {
+                    A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
+                    if (j < S) {
+                        const bool own = own_valid && j == h.own_id;
+                        const SurfF sf = a.surf[j];
+                        if (STYPE(j) == RT_SURF_SPHERE) {
+                            const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
+                            const float c = dot(oc, oc) - sf.a.w;
+                            const float r = sf.c.x;
+                            // closest approach of the axis P->L to the centre, at parameter t; the sample
+                            // segments fan out linearly (deviation s*rho at parameter s), and a point of
+                            // contact needs |s - t|*llen <= r + s*rho, which bounds s by s_hi
+                            const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
+                            const f3 q = oc + lrel * t;
+                            const float reach = r + rho * fminf(1.f, s_hi_scale * (r + t * llen));
+                            const bool never = own || !lit || dot(q, q) > reach * reach * 1.0002f;
+                            if (!never) {
+                                const float lmin = llen - rho;
+                                const bool linear_ok = c >= 1e-3f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
+                                if (!linear_ok) gen = true;
+                                else {
+                                    const float k = -__builtin_amdgcn_rsqf(c);
+                                    A[j] = dot(lrel, oc) * k; B[j] = dot(right, oc) * k; C[j] = dot(up, oc) * k;
+                                    lin |= 1u << j;
+                                }
+                            }
+                        } else if (STYPE(j) == RT_SURF_PLANE) {
+                            const f3 n = F3(sf.a.x, sf.a.y, sf.a.z);
+                            const float hh = sf.a.w - dot(P, n);
+                            const float ah = fabsf(hh);
+                            const float sg = hh < 0.f ? -1.f : 1.f;
+                            const float dn0 = dot(lrel, n) * sg;  // > |h|  <=>  L is on the far side
+                            const bool never = own || !lit || (ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0));
+                            if (!never) {
+                                if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho))) gen = true;
+                                else {
+                                    A[j] = dn0 - ah; B[j] = dot(right, n) * sg; C[j] = dot(up, n) * sg;
+                                    lin |= 1u << j;
+                                }
+                            }
+                        } else {
+                            if (!lit) {
+                            } else if (own) {
+                                if (dot(lrel, h.nrm) - rho < 0.f) gen = true;  // some sample may enter the box
+                            } else {
+                                const f3 oc = P - F3(sf.c.x, sf.c.y, sf.c.z);  // bounding sphere
+                                const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
+                                const f3 q = oc + lrel * t;
+                                const float reach = sf.c.w + rho;
+                                if (!(dot(q, q) > reach * reach * 1.0002f)) gen = true;
+                            }
+                        }
+                    }
+                }
+                A[SMALL_MAX] = -INFINITY; B[SMALL_MAX] = 0.f; C[SMALL_MAX] = 0.f;
+                if (own_sph_blocks && lit) {
+                    const float r = own_sf.c.x;
+                    const float dl = dot(lrel, ov);
+                    if (dl - rho * r * 1.0002f < 0.f) {  // some sample may enter the own sphere
+                        if (llen - rho > 2.0002f * r) {
+                            const float k = -2.0e6f;      // far root -2 w.oc > 1e-6  <=>  -sv.oc * 2e6 > len
+                            A[SMALL_MAX] = dl * k; B[SMALL_MAX] = dot(right, ov) * k; C[SMALL_MAX] = dot(up, ov) * k;
+                            lin |= 1u << SMALL_MAX;
+                        } else gen = true;
+                    }
+                }
+                uint32_t cand = 0;
+#pragma unroll
+                for (int s = 0; s < NSLOT; ++s)
+                    if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
+                const int k = __popc(cand);
+                defer = __any(gen) || k > KMAX;
+                if (!defer) {
+                    if (lane == 0) atomicAdd(&a.counters[k == 0 ? CNT_WL_NONE : (k <= 4 ? CNT_WL_NONE + k : CNT_WL_K4)], 1ull);
+                    if (k > 0) {
+                        // ---- compact the wave's candidate tests into register triples
+                        float Ad[KMAX], Bd[KMAX], Cd[KMAX], tmd[KMAX], trd[KMAX];
+                        uint32_t rem = cand;
+#pragma unroll
+                        for (int e = 0; e < KMAX; ++e) {
+                            const int sl = rem ? (int)__builtin_ctz(rem) : -1;
+                            rem &= rem - 1u;
+                            Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; tmd[e] = 1.f; trd[e] = 1.f;
+#pragma unroll
+                            for (int t = 0; t < NSLOT; ++t) {
+                                if (sl == t) {
+                                    Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t];
+                                    if (t < SMALL_MAX) {
+                                        tmd[e] = STYPE(t < SMALL_MAX ? t : 0) == RT_SURF_PLANE ? 0.f : 1.f;
+                                        if (!ALL_OPAQUE) trd[e] = a.surf[t < SMALL_MAX ? t : 0].transp;
+                                    }
+                                }
+                            }
+                            if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.transp;
+                        }
+                        const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
+                        const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
+                        const float koff = -0.5f * lt.radius;
+                        float sum;
+                        switch (k) {
+                            case 1: sum = compact_samples<1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 2: sum = compact_samples<2, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 3: sum = compact_samples<3, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 4: sum = compact_samples<4, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 5: sum = compact_samples<5, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 6: sum = compact_samples<6, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 7: sum = compact_samples<7, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            default: sum = compact_samples<8, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                        }
+                        ratio = sum * inv_n2;
+                    }
+                }
+            }
+            if (defer) {
+                if (lane == 0) {
+                    const uint32_t slot = atomicAdd(a.deferred_count, 1u);
+                    a.deferred[slot] = make_uint2(base, (uint32_t)l);
+                    atomicAdd(&a.counters[lt.point_path ? CNT_WL_POINT : CNT_WL_GENERIC], 1ull);
+                }
+            } else {
+                phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+            }
+        }
+        if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
+            const uint32_t lp = a.q.pixel[idx];
+            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
+            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+        }
+    }
+}
+
+template <bool HAS_BOX, bool ALL_OPAQUE>
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
+    uint32_t count = *a.q.count;
+    if (count > a.q.capacity) count = a.q.capacity;
+    const uint32_t n_items = *a.deferred_count;
+    const int S = a.fp.n_surfaces, N = a.fp.n_shadow;
+    const float invN = 1.0f / (float)N;
+    const float inv_n2 = 1.0f / (float)(N * N);
+    const uint32_t lane = threadIdx.x & 63;
+
     uint32_t tword = 0;
     float str[SMALL_MAX];
 #pragma unroll
@@ -285,177 +582,164 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_small(ShadeArgs a) {
         tword |= ty << (4 * j);
     }
     tword = __builtin_amdgcn_readfirstlane(tword);
-#define STYPE(j) ((tword >> (4 * (j))) & 0xFu)
 
-    for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(a.work2, 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= n_items) break;
+        const uint2 it = a.deferred[item];
+        const uint32_t base = __builtin_amdgcn_readfirstlane(it.x);
+        const int l = (int)__builtin_amdgcn_readfirstlane(it.y);
         const uint32_t idx = base + lane;
         const bool active = idx < count;
-        const uint32_t li = active ? idx : base;
-        const f3 P = F3(a.q.px[li], a.q.py[li], a.q.pz[li]);
-        const f3 nrm = F3(a.q.nx[li], a.q.ny[li], a.q.nz[li]);
-        const f3 view = F3(a.q.vx[li], a.q.vy[li], a.q.vz[li]);
-        const uint32_t gpix = a.q.gpixel[li], node = a.q.node[li], meta = a.q.meta[li];
-        const uint32_t flags = meta >> 24;
-        const int own_id = (flags & HF_NO_OWN) ? -1 : (int)(meta & 0xFFFFFFu);
-        const SurfF own_sf = a.surf[meta & 0xFFFFFFu];
+        const HitRec h = load_hit(a.q, active ? idx : base);
+        const f3 P = h.P;
+        const uint32_t flags = h.flags;
+        const int own_id = (flags & HF_NO_OWN) ? -1 : h.own_id;
+        const SurfF own_sf = a.surf[h.own_id];
         const MatF m = a.mat[own_sf.mat];
-
-        // ---- per-(hit, surface) constants
-        float g[SMALL_MAX][HAS_BOX ? 6 : 4];
-#pragma unroll
-        for (int j = 0; j < SMALL_MAX; ++j) {
-#pragma unroll
-            for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
-            if (j < S) {
-                const SurfF sf = a.surf[j];
-                const bool own = j == own_id;
-                if (STYPE(j) == RT_SURF_SPHERE) {
-                    const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
-                    g[j][0] = oc.x; g[j][1] = oc.y; g[j][2] = oc.z;
-                    g[j][3] = own ? -INFINITY : 0.f - (dot(oc, oc) - sf.a.w);
-                } else if (STYPE(j) == RT_SURF_PLANE) {
-                    g[j][0] = sf.a.x; g[j][1] = sf.a.y; g[j][2] = sf.a.z;
-                    g[j][3] = own ? NAN : sf.a.w - dot(P, F3(sf.a.x, sf.a.y, sf.a.z));
-                } else if (HAS_BOX) {
-                    g[j][0] = own ? 1e30f : sf.a.x - P.x; g[j][1] = own ? 1e30f : sf.a.y - P.y; g[j][2] = own ? 1e30f : sf.a.z - P.z;
-                    g[j][3] = own ? 1e30f : sf.b.x - P.x; g[j][4] = own ? 1e30f : sf.b.y - P.y; g[j][5] = own ? 1e30f : sf.b.z - P.z;
-                }
+        const LightF lt = a.light[l];
+        const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+        const float lc2 = dot(lrel, lrel);
+        const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
+        const f3 ldir = lrel * linv;
+        float ratio;
+        if (lt.point_path) {
+            // ---- one ray to the light centre (ray_tracer.py:36-48), literal form
+            const float dist = lc2 * linv;
+            float f = 1.f;
+            for (int s = 0; s < S; ++s) {
+                const SurfF sf = a.surf[s];
+                const bool own = s == own_id;
+                bool blk;
+                if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
+                else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
+                else blk = box_blocks_a(sf, P, ldir, dist, own, h.nrm, flags);
+                f = blk ? f * sf.transp : f;
             }
-        }
-        // ---- own-surface rule operands (per lane)
-        const bool own_sphere = own_id >= 0 && own_sf.type == RT_SURF_SPHERE;
-        const bool own_box = HAS_BOX && own_id >= 0 && own_sf.type == RT_SURF_BOX;
-        // sphere: oc; box: outward normal.  w . ov < 0  <=>  the sample enters the body
-        const f3 ov = own_sphere ? P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z) : nrm;
-        const bool own_sph_blocks_b = own_sphere && !(flags & HF_CBATCH_POS);
-        const bool own_sph_blocks_a = own_sphere && !(flags & HF_CDOT_POS);
-        const float own_tr = own_sf.transp;
-        float ob[6];
+            ratio = f;
+        } else {
+            // ---- per-(hit, surface) constants
+            float g[SMALL_MAX][HAS_BOX ? 6 : 4];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) ob[c] = 0.f;
-        if (HAS_BOX && own_box) {
-            ob[0] = own_sf.a.x - P.x; ob[1] = own_sf.a.y - P.y; ob[2] = own_sf.a.z - P.z;
-            ob[3] = own_sf.b.x - P.x; ob[4] = own_sf.b.y - P.y; ob[5] = own_sf.b.z - P.z;
-        }
-
-        f3 color = F3(0.f, 0.f, 0.f);
-        for (int l = 0; l < L; ++l) {
-            const LightF lt = a.light[l];
-            const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
-            const float lc2 = dot(lrel, lrel);
-            const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
-            const f3 ldir = lrel * linv;
-            float ratio;
-            if (lt.point_path) {
-                // ---- one ray to the light centre (ray_tracer.py:36-48); rare path, literal form
-                const float dist = lc2 * linv;
-                float f = 1.f;
-                for (int s = 0; s < S; ++s) {
-                    const SurfF sf = a.surf[s];
-                    const bool own = s == own_id;
-                    bool blk;
-                    if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
-                    else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
-                    else blk = box_blocks_a(sf, P, ldir, dist, own, nrm, flags);
-                    f = blk ? f * sf.transp : f;
-                }
-                ratio = f;
-            } else {
-                const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
-                const f3 right = normalize(cross(ldir, perp));
-                const f3 up = normalize(cross(right, ldir));
-                const uint32_t key = rt_grid_key(a.fp.seed_key, gpix, node, (uint32_t)l);
-                const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
-                float sum = 0.f;
-                uint32_t ctr = key;
-                for (int i = 0; i < N; ++i) {
-                    const float cu = ((float)i * invN - 0.5f) * lt.radius;
-                    for (int j = 0; j < N; ++j) {
-                        uint32_t ub, vb;
-                        rt_sample_bits(ctr, 0u, ub, vb);
-                        ctr += 0x9E3779B9u;
-                        const float cv = ((float)j * invN - 0.5f) * lt.radius;
-                        const float ur = fmaf((float)ub, ku, cu);
-                        const float vr = fmaf((float)vb, ku, cv);
-                        const f3 sv = F3(fmaf(up.x, vr, fmaf(right.x, ur, lrel.x)), fmaf(up.y, vr, fmaf(right.y, ur, lrel.y)),
-                                         fmaf(up.z, vr, fmaf(right.z, ur, lrel.z)));
-                        const float d2 = dot(sv, sv);
-                        const float dinv = __builtin_amdgcn_rsqf(d2);
-                        const f3 w = sv * dinv;
-                        const float dist = d2 * dinv;
-                        float iw[3] = {0.f, 0.f, 0.f};
-                        if (HAS_BOX) {
-                            // |w_a| < 1e-6 is "parallel" (cube.py:129); clamping the magnitude keeps the slab logic
-                            // branch-free: inside the slab both plane distances become huge with opposite signs
-                            iw[0] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.x), RT_EPSF), w.x));
-                            iw[1] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.y), RT_EPSF), w.y));
-                            iw[2] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.z), RT_EPSF), w.z));
-                        }
-                        bool any = false;
-                        float f = 1.f;
+            for (int j = 0; j < SMALL_MAX; ++j) {
 #pragma unroll
-                        for (int s = 0; s < SMALL_MAX; ++s) {
-                            if (s < S) {
-                                bool blk;
-                                if (STYPE(s) == RT_SURF_SPHERE) {
-                                    const float b = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
-                                    const float disc = fmaf(b, b, g[s][3]);
-                                    const float sq = __builtin_amdgcn_sqrtf(disc);  // NaN when the ray misses
-                                    const float ssq = copysignf(sq, g[s][3]);       // outside: near root, inside: far root
-                                    const float tn = ssq - b;
-                                    blk = tn > RT_EPSF && tn < dist;
-                                } else if (STYPE(s) == RT_SURF_PLANE) {
-                                    const float denom = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
-                                    const float t = g[s][3] * __builtin_amdgcn_rcpf(denom);
-                                    blk = fabsf(denom) >= RT_EPSF && t > RT_EPSF && t < dist;
-                                } else if (HAS_BOX) {
-                                    const float t1x = g[s][0] * iw[0], t2x = g[s][3] * iw[0];
-                                    const float t1y = g[s][1] * iw[1], t2y = g[s][4] * iw[1];
-                                    const float t1z = g[s][2] * iw[2], t2z = g[s][5] * iw[2];
-                                    const float tnear = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
-                                    const float tfar = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
-                                    const float t = tnear > RT_EPSF ? tnear : tfar;   // cube.py:167-168
-                                    blk = tnear <= tfar && t > RT_EPSF && t < dist;
-                                } else blk = false;
-                                if (ALL_OPAQUE) any = any || blk;
-                                else f = blk ? f * str[s] : f;
-                            }
-                        }
-                        // ---- the hit's own surface, by rule (see the header of this file)
-                        {
-                            const float bo = fmaf(w.z, ov.z, fmaf(w.y, ov.y, w.x * ov.x));
-                            const float t2 = -2.f * bo;
-                            bool blk = own_sph_blocks_b && bo < 0.f && t2 > RT_EPSF && t2 < dist;
-                            if (HAS_BOX) {
-                                const float t2x = fmaxf(ob[0] * iw[0], ob[3] * iw[0]);
-                                const float t2y = fmaxf(ob[1] * iw[1], ob[4] * iw[1]);
-                                const float t2z = fmaxf(ob[2] * iw[2], ob[5] * iw[2]);
-                                const float tfar = fminf(fminf(t2x, t2y), t2z);
-                                blk = blk || (own_box && bo < 0.f && tfar > RT_EPSF && tfar < dist);
-                            }
-                            if (ALL_OPAQUE) any = any || blk;
-                            else f = blk ? f * own_tr : f;
-                        }
-                        if (ALL_OPAQUE) sum += any ? 0.f : 1.f;
-                        else sum += f;
+                for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
+                if (j < S) {
+                    const SurfF sf = a.surf[j];
+                    const bool own = j == own_id;
+                    if (STYPE(j) == RT_SURF_SPHERE) {
+                        const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
+                        g[j][0] = oc.x; g[j][1] = oc.y; g[j][2] = oc.z;
+                        g[j][3] = own ? -INFINITY : 0.f - (dot(oc, oc) - sf.a.w);
+                    } else if (STYPE(j) == RT_SURF_PLANE) {
+                        g[j][0] = sf.a.x; g[j][1] = sf.a.y; g[j][2] = sf.a.z;
+                        g[j][3] = own ? NAN : sf.a.w - dot(P, F3(sf.a.x, sf.a.y, sf.a.z));
+                    } else if (HAS_BOX) {
+                        g[j][0] = own ? 1e30f : sf.a.x - P.x; g[j][1] = own ? 1e30f : sf.a.y - P.y; g[j][2] = own ? 1e30f : sf.a.z - P.z;
+                        g[j][3] = own ? 1e30f : sf.b.x - P.x; g[j][4] = own ? 1e30f : sf.b.y - P.y; g[j][5] = own ? 1e30f : sf.b.z - P.z;
                     }
                 }
-                ratio = sum * inv_n2;
             }
-            const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
-            if (inten != 0.f) {
-                const float ndl = fmaxf(0.f, dot(nrm, ldir));
-                const float k2 = 2.f * dot(ldir, nrm);
-                const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
-                const float rv = dot(rdir, view);
-                const float sp = rv > 0.f ? powf(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
-                const float spi = sp * lt.spec;
-                color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
-                color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
-                color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
+            // ---- own-surface rule operands
+            const bool own_sphere = own_id >= 0 && own_sf.type == RT_SURF_SPHERE;
+            const bool own_box = HAS_BOX && own_id >= 0 && own_sf.type == RT_SURF_BOX;
+            // sphere: oc; box: outward normal.  w . ov < 0  <=>  the sample enters the body
+            const f3 ov = own_sphere ? P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z) : h.nrm;
+            const bool own_sph_blocks_b = own_sphere && !(flags & HF_CBATCH_POS);
+            const float own_tr = own_sf.transp;
+            float ob[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) ob[c] = 0.f;
+            if (HAS_BOX && own_box) {
+                ob[0] = own_sf.a.x - P.x; ob[1] = own_sf.a.y - P.y; ob[2] = own_sf.a.z - P.z;
+                ob[3] = own_sf.b.x - P.x; ob[4] = own_sf.b.y - P.y; ob[5] = own_sf.b.z - P.z;
             }
+            const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
+            const f3 right = normalize(cross(ldir, perp));
+            const f3 up = normalize(cross(right, ldir));
+            const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
+            const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
+            float sum = 0.f;
+            uint32_t ctr = key;
+            for (int i = 0; i < N; ++i) {
+                const float cu = ((float)i * invN - 0.5f) * lt.radius;
+                for (int j = 0; j < N; ++j) {
+                    uint32_t ub, vb;
+                    rt_sample_bits(ctr, 0u, ub, vb);
+                    ctr += 0x9E3779B9u;
+                    const float cv = ((float)j * invN - 0.5f) * lt.radius;
+                    const float ur = fmaf((float)ub, ku, cu);
+                    const float vr = fmaf((float)vb, ku, cv);
+                    const f3 sv = F3(fmaf(up.x, vr, fmaf(right.x, ur, lrel.x)), fmaf(up.y, vr, fmaf(right.y, ur, lrel.y)),
+                                     fmaf(up.z, vr, fmaf(right.z, ur, lrel.z)));
+                    const float d2 = dot(sv, sv);
+                    const float dinv = __builtin_amdgcn_rsqf(d2);
+                    const f3 w = sv * dinv;
+                    const float dist = d2 * dinv;
+                    float iw[3] = {0.f, 0.f, 0.f};
+                    if (HAS_BOX) {
+                        // |w_a| < 1e-6 is "parallel" (cube.py:129); clamping the magnitude keeps the slab logic
+                        // branch-free: inside the slab both plane distances become huge with opposite signs
+                        iw[0] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.x), RT_EPSF), w.x));
+                        iw[1] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.y), RT_EPSF), w.y));
+                        iw[2] = __builtin_amdgcn_rcpf(copysignf(fmaxf(fabsf(w.z), RT_EPSF), w.z));
+                    }
+                    bool any = false;
+                    float f = 1.f;
+#pragma unroll
+                    for (int s = 0; s < SMALL_MAX; ++s) {
+                        if (s < S) {
+                            bool blk;
+                            if (STYPE(s) == RT_SURF_SPHERE) {
+                                const float b = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
+                                const float disc = fmaf(b, b, g[s][3]);
+                                const float sq = __builtin_amdgcn_sqrtf(disc);  // NaN when the ray misses
+                                const float ssq = copysignf(sq, g[s][3]);       // outside: near root, inside: far root
+                                const float tn = ssq - b;
+                                blk = tn > RT_EPSF && tn < dist;
+                            } else if (STYPE(s) == RT_SURF_PLANE) {
+                                const float denom = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
+                                const float t = g[s][3] * __builtin_amdgcn_rcpf(denom);
+                                blk = fabsf(denom) >= RT_EPSF && t > RT_EPSF && t < dist;
+                            } else if (HAS_BOX) {
+                                const float t1x = g[s][0] * iw[0], t2x = g[s][3] * iw[0];
+                                const float t1y = g[s][1] * iw[1], t2y = g[s][4] * iw[1];
+                                const float t1z = g[s][2] * iw[2], t2z = g[s][5] * iw[2];
+                                const float tnear = fmaxf(fmaxf(fminf(t1x, t2x), fminf(t1y, t2y)), fminf(t1z, t2z));
+                                const float tfar = fminf(fminf(fmaxf(t1x, t2x), fmaxf(t1y, t2y)), fmaxf(t1z, t2z));
+                                const float t = tnear > RT_EPSF ? tnear : tfar;   // cube.py:167-168
+                                blk = tnear <= tfar && t > RT_EPSF && t < dist;
+                            } else blk = false;
+                            if (ALL_OPAQUE) any = any || blk;
+                            else f = blk ? f * str[s] : f;
+                        }
+                    }
+                    // ---- the hit's own surface, by rule (see the header of this file)
+                    {
+                        const float bo = fmaf(w.z, ov.z, fmaf(w.y, ov.y, w.x * ov.x));
+                        const float t2 = -2.f * bo;
+                        bool blk = own_sph_blocks_b && bo < 0.f && t2 > RT_EPSF && t2 < dist;
+                        if (HAS_BOX) {
+                            const float t2x = fmaxf(ob[0] * iw[0], ob[3] * iw[0]);
+                            const float t2y = fmaxf(ob[1] * iw[1], ob[4] * iw[1]);
+                            const float t2z = fmaxf(ob[2] * iw[2], ob[5] * iw[2]);
+                            const float tfar = fminf(fminf(t2x, t2y), t2z);
+                            blk = blk || (own_box && bo < 0.f && tfar > RT_EPSF && tfar < dist);
+                        }
+                        if (ALL_OPAQUE) any = any || blk;
+                        else f = blk ? f * own_tr : f;
+                    }
+                    if (ALL_OPAQUE) sum += any ? 0.f : 1.f;
+                    else sum += f;
+                }
+            }
+            ratio = sum * inv_n2;
         }
-        if (active) {
+        f3 color = F3(0.f, 0.f, 0.f);
+        phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+        if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
             const uint32_t lp = a.q.pixel[idx];
             unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
             unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
@@ -468,12 +752,16 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
     const dim3 g(blocks), b(SHADE_BLOCK);
     if (a.variant == SHADE_GENERAL || a.fp.n_surfaces > SMALL_MAX) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
-    } else if (a.has_box) {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_small<true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_small<true, false>), g, b, 0, s, a);
+        return;
+    }
+    if (a.all_opaque) hipLaunchKernelGGL(k_shade_fast<true>, g, b, 0, s, a);
+    else hipLaunchKernelGGL(k_shade_fast<false>, g, b, 0, s, a);
+    if (a.has_box) {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_deferred<true, false>), g, b, 0, s, a);
     } else {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_small<false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_small<false, false>), g, b, 0, s, a);
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_deferred<false, false>), g, b, 0, s, a);
     }
 }
 

@@ -46,11 +46,13 @@ class RtStats(C.Structure):
         ("shaded_points", C.c_uint64), ("shadow_rays", C.c_uint64), ("rows_rendered", C.c_uint64),
         ("bands", C.c_uint32), ("reserved", C.c_uint32),
         ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
-        ("ms_resolve", C.c_double), ("flop_shade", C.c_double),
+        ("ms_resolve", C.c_double), ("flop_shade", C.c_double), ("wave_light", C.c_uint64 * 8),
     ]
 
     def as_dict(self):
-        return {name: getattr(self, name) for name, _ in self._fields_ if name != "reserved"}
+        d = {name: getattr(self, name) for name, _ in self._fields_ if name not in ("reserved", "wave_light")}
+        d["wave_light"] = list(self.wave_light)
+        return d
 
     @property
     def total_rays(self):
