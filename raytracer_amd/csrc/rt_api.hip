@@ -181,7 +181,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     fp.row_y = h->d_row_y;
 
     HIP_TRY(h, hipEventRecord(h->ev[0], st));
-    const int max_blocks = h->n_cu * 8;
+    const int max_blocks = h->n_cu * 4;
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
     for (int d = 0; d < depths; ++d) {
         TraceArgs ta{};
@@ -193,7 +193,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         // the queue this depth fills must start empty (it was the input two depths ago)
         HIP_TRY(h, hipMemsetAsync(ta.out.count, 0, sizeof(uint32_t), st));
         int blocks = max_blocks;
-        if (d == 0) blocks = (int)std::min<size_t>((pixels + 255) / 256, (size_t)max_blocks);
+        if (d == 0) blocks = (int)std::min<size_t>((pixels + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[1], st));

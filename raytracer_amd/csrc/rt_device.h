@@ -6,6 +6,7 @@
 
 #define RT_EPS 1e-6   // /root/reference/utils.py:6
 #define RT_EPSF 1e-6f
+#define RT_TRACE_BLOCK 512  // threads per workgroup of the ray-tree kernel
 
 // ---- float64 surface record used by the ray-tree kernel -------------------------
 // One 64-byte record per surface, file order.  All lanes of a wave test the same

@@ -386,12 +386,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
     tword = __builtin_amdgcn_readfirstlane(tword);
 #define STYPE(j) ((tword >> (4 * (j))) & 0xFu)
 
-    // waves pull 64 hits at a time from a shared counter: classification makes the cost per hit uneven
+    // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
+    // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
+    uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t grab = 0, grab_end = 0;
     for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.work, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (base >= count) break;
+        if (grab >= grab_end) {
+            uint32_t g0 = 0;
+            if (lane == 0) g0 = atomicAdd(a.work, 256u);
+            grab = __builtin_amdgcn_readfirstlane(g0);
+            grab_end = grab + 256u;
+            if (grab >= count) break;
+        }
+        const uint32_t base = grab;
+        grab += 64u;
+        if (base >= count) { grab = grab_end; continue; }
         const uint32_t idx = base + lane;
         const bool active = idx < count;
         const HitRec h = load_hit(a.q, active ? idx : base);  // idle lanes shadow the chunk's first hit, results dropped
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                 const int k = __popc(cand);
                 defer = __any(gen) || k > KMAX;
                 if (!defer) {
-                    if (lane == 0) atomicAdd(&a.counters[k == 0 ? CNT_WL_NONE : (k <= 4 ? CNT_WL_NONE + k : CNT_WL_K4)], 1ull);
+                    wl_n[k <= 4 ? k : 4] += 1;
                     if (k > 0) {
                         // ---- compact the wave's candidate tests into register triples
                         float Ad[KMAX], Bd[KMAX], Cd[KMAX], tmd[KMAX], trd[KMAX];
@@ -547,8 +556,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(a.deferred_count, 1u);
                     a.deferred[slot] = make_uint2(base, (uint32_t)l);
-                    atomicAdd(&a.counters[lt.point_path ? CNT_WL_POINT : CNT_WL_GENERIC], 1ull);
                 }
+                wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
                 phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
             }
@@ -559,6 +568,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
             unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
             unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
         }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
     }
 }
 

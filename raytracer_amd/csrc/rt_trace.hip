@@ -27,7 +27,7 @@
 
 #pragma clang fp contract(off)
 
-#define TRACE_BLOCK 256
+#define TRACE_BLOCK RT_TRACE_BLOCK
 #define SURF_TILE 512  // 512 x 64 B = 32 KiB of LDS per workgroup
 
 struct d3 { double x, y, z; };
@@ -123,6 +123,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
 template <bool PRIMARY>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     __shared__ SurfD tile[SURF_TILE];
+    __shared__ uint32_t s_cnt[3][TRACE_BLOCK / 64];
+    __shared__ uint32_t s_base[3];
     const int S = a.fp.n_surfaces;
     const int W = a.fp.width;
     uint32_t count;
@@ -232,7 +234,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                     double sg = pos ? 1.0 : -1.0;
                     n = D3(ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0);
                     double pa = ax == 0 ? P.x : (ax == 1 ? P.y : P.z);
-                    double face = sf.d[(pos ? 3 : 0) + ax];
+                    double face = pos ? (ax == 0 ? sf.d[3] : (ax == 1 ? sf.d[4] : sf.d[5]))
+                                      : (ax == 0 ? sf.d[0] : (ax == 1 ? sf.d[1] : sf.d[2]));
                     if (pos ? (pa > face) : (pa < face)) flags |= HF_BOX_OUTSIDE;
                 }
             }
@@ -256,38 +259,59 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
             unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(tb * a.fp.bg[2]));
         }
 
+        // ---- reserve queue slots: ONE atomic per workgroup and queue ------------------------------
+        // (a single counter word sustains only ~90 atomics/us: per-wave reservations of three
+        //  queues would serialise the whole kernel on those three words)
+        const bool want_r = hit && m.has_refl;
+        const bool want_t = hit && m.transp > 0.f;
+        const bool push_s = hit, push_r = want_r && !child_cut, push_t = want_t && !child_cut;
+        const unsigned long long bs_ = __ballot(push_s), br_ = __ballot(push_r), bt_ = __ballot(push_t);
+        const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(bs_); s_cnt[1][wv] = (uint32_t)__popcll(br_); s_cnt[2][wv] = (uint32_t)__popcll(bt_); }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int q = threadIdx.x;
+            uint32_t total = 0;
+#pragma unroll
+            for (int w = 0; w < TRACE_BLOCK / 64; ++w) { const uint32_t c = s_cnt[q][w]; s_cnt[q][w] = total; total += c; }
+            uint32_t* counter = q == 0 ? a.shade.count : a.out.count;
+            // reflection and transparency children share the output queue: two disjoint reservations
+            s_base[q] = total ? atomicAdd(counter, total) : 0u;
+        }
+        __syncthreads();
+        const uint32_t slot_s = s_base[0] + s_cnt[0][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
+        const uint32_t slot_r = s_base[1] + s_cnt[1][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(br_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br_, 0u));
+        const uint32_t slot_t = s_base[2] + s_cnt[2][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bt_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bt_, 0u));
+        __syncthreads();  // s_cnt / s_base are rewritten by the next iteration
+
         // ---- shading record -----------------------------------------------------------
-        {
-            uint32_t slot = wave_append(a.shade.count, hit);
-            if (hit) {
-                if (slot < a.shade.capacity) {
-                    d3 view = normalize(sub(o, P));  // ray_tracer.py:275
-                    float om = (float)(1.0 - (double)m.transp);  // material.py:28
-                    a.shade.px[slot] = (float)P.x; a.shade.py[slot] = (float)P.y; a.shade.pz[slot] = (float)P.z;
-                    a.shade.nx[slot] = (float)n.x; a.shade.ny[slot] = (float)n.y; a.shade.nz[slot] = (float)n.z;
-                    a.shade.vx[slot] = (float)view.x; a.shade.vy[slot] = (float)view.y; a.shade.vz[slot] = (float)view.z;
-                    a.shade.wr[slot] = tr * om; a.shade.wg[slot] = tg * om; a.shade.wb[slot] = tb * om;
-                    a.shade.pixel[slot] = lpix; a.shade.gpixel[slot] = gpix; a.shade.node[slot] = node;
-                    a.shade.meta[slot] = (uint32_t)bs | (flags << 24);
-                    n_shaded += 1;
-                } else ovf_shade += 1;
-            }
+        if (push_s) {
+            if (slot_s < a.shade.capacity) {
+                const uint32_t slot = slot_s;
+                d3 view = normalize(sub(o, P));  // ray_tracer.py:275
+                float om = (float)(1.0 - (double)m.transp);  // material.py:28
+                a.shade.px[slot] = (float)P.x; a.shade.py[slot] = (float)P.y; a.shade.pz[slot] = (float)P.z;
+                a.shade.nx[slot] = (float)n.x; a.shade.ny[slot] = (float)n.y; a.shade.nz[slot] = (float)n.z;
+                a.shade.vx[slot] = (float)view.x; a.shade.vy[slot] = (float)view.y; a.shade.vz[slot] = (float)view.z;
+                a.shade.wr[slot] = tr * om; a.shade.wg[slot] = tg * om; a.shade.wb[slot] = tb * om;
+                a.shade.pixel[slot] = lpix; a.shade.gpixel[slot] = gpix; a.shade.node[slot] = node;
+                a.shade.meta[slot] = (uint32_t)bs | (flags << 24);
+                n_shaded += 1;
+            } else ovf_shade += 1;
         }
 
         // ---- reflection child (ray_tracer.py:192-207) ---------------------------------------
         {
-            const bool want = hit && m.has_refl;
             const float cr = tr * m.kr[0], cg = tg * m.kr[1], cb = tb * m.kr[2];
-            if (want && child_cut) {  // depth limit: the child returns the background untraced (:261-262)
+            if (want_r && child_cut) {  // depth limit: the child returns the background untraced (:261-262)
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 0], (double)(cr * a.fp.bg[0]));
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 1], (double)(cg * a.fp.bg[1]));
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(cb * a.fp.bg[2]));
                 n_cut += 1;
             }
-            const bool push = want && !child_cut;
-            uint32_t slot = wave_append(a.out.count, push);
-            if (push) {
-                if (slot < a.out.capacity) {
+            if (push_r) {
+                if (slot_r < a.out.capacity) {
+                    const uint32_t slot = slot_r;
                     d3 rd = sub(d, scl(n, 2 * dotb(d, n)));  // ray_tracer.py:126
                     d3 ro = add(P, scl(n, RT_EPS));          // ray_tracer.py:198
                     a.out.ox[slot] = ro.x; a.out.oy[slot] = ro.y; a.out.oz[slot] = ro.z;
@@ -299,18 +323,16 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         }
         // ---- transparency child (ray_tracer.py:226-239) -------------------------------------
         {
-            const bool want = hit && m.transp > 0.f;
             const float cr = tr * m.transp, cg = tg * m.transp, cb = tb * m.transp;
-            if (want && child_cut) {
+            if (want_t && child_cut) {
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 0], (double)(cr * a.fp.bg[0]));
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 1], (double)(cg * a.fp.bg[1]));
                 unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(cb * a.fp.bg[2]));
                 n_cut += 1;
             }
-            const bool push = want && !child_cut;
-            uint32_t slot = wave_append(a.out.count, push);
-            if (push) {
-                if (slot < a.out.capacity) {
+            if (push_t) {
+                if (slot_t < a.out.capacity) {
+                    const uint32_t slot = slot_t;
                     d3 to = add(P, scl(d, RT_EPS));  // ray_tracer.py:230
                     a.out.ox[slot] = to.x; a.out.oy[slot] = to.y; a.out.oz[slot] = to.z;
                     a.out.dx[slot] = d.x; a.out.dy[slot] = d.y; a.out.dz[slot] = d.z;
