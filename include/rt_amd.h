@@ -172,9 +172,9 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
                   uint32_t* count);
 
 /* Jitter stream contract, exported so tests can pin host == device == oracle.
- * Writes the two 24-bit integers of sample s of grid (seed,pixel,node,light).       */
+ * Writes the two 16-bit integers of sample s of grid (seed,pixel,node,light).       */
 void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s,
-                    uint32_t* u24, uint32_t* v24);
+                    uint32_t* u16, uint32_t* v16);
 
 #ifdef __cplusplus
 }

@@ -18,8 +18,9 @@ both sides are driven by a stream keyed on *what* is being sampled instead of
     draw  = 2*(i*N+j) + axis   (axis 0 = u, 1 = v), i outer / j inner as in
             light.py:51-52
 
-Every value is a 24-bit integer scaled by 2**-24, so it is exact in float32 and
-float64 alike.
+One 32-bit hash per sample yields both coordinates: u from its high 16 bits, v
+from its low 16 bits.  Every value is a 16-bit integer scaled by 2**-16, so it is
+exact in float32 and float64 alike (and so is cell index + value for N < 256).
 """
 
 M32 = 0xFFFFFFFF
@@ -47,14 +48,12 @@ def stream_key(seed: int, pixel: int, node: int, light: int) -> int:
 
 
 def sample_bits(key: int, s: int):
-    """The two 24-bit integers (u, v) of sample ``s = i*N+j`` of a grid."""
+    """The two 16-bit integers (u, v) of sample ``s = i*N+j`` of a grid."""
     m = mix32((key + s * GOLDEN) & M32)
-    u = m >> 8
-    v = (((m ^ 0x68E31DA4) * 0x2C9277B5) & M32) >> 8
-    return u, v
+    return m >> 16, m & 0xFFFF
 
 
 def uniform(seed: int, pixel: int, node: int, light: int, draw: int) -> float:
     """Value handed to the reference in place of ``np.random.random()``."""
     u, v = sample_bits(stream_key(seed, pixel, node, light), draw >> 1)
-    return (v if (draw & 1) else u) * (1.0 / 16777216.0)
+    return (v if (draw & 1) else u) * (1.0 / 65536.0)

@@ -275,7 +275,7 @@ def item_kat(pool, only):
     for seed, pixel, node, light, s in [(0, 0, 1, 0, 0), (0, 1, 1, 0, 0), (0, 123456, 1, 4, 24), (7, 8294399, 2, 1, 255),
                                         (0xFFFFFFFF, 42, 1023, 0, 3), (1, 2, 3, 4, 5), (0, 250000, 5, 2, 17), (99, 77, 6, 0, 1)]:
         u, v = jitter.sample_bits(jitter.stream_key(seed, pixel, node, light), s)
-        table.append({"seed": seed, "pixel": pixel, "node": node, "light": light, "s": s, "u24": u, "v24": v})
+        table.append({"seed": seed, "pixel": pixel, "node": node, "light": light, "s": s, "u": u, "v": v})
     with open(os.path.join(GOLD, "kat", "jitter_kat.json"), "w") as f:
         json.dump(table, f, indent=1)
     print("kat done", len(kinds), flush=True)

@@ -109,12 +109,12 @@ static inline uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t node, 
 }
 static inline void sample_bits(uint32_t key, uint32_t s, uint32_t* u, uint32_t* v) {
     uint32_t m = mix32(key + s * 0x9E3779B9u);
-    *u = m >> 8;
-    *v = ((m ^ 0x68E31DA4u) * 0x2C9277B5u) >> 8;
+    *u = m >> 16;
+    *v = m & 0xFFFFu;
 }
 void rto_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s,
-                     uint32_t* u24, uint32_t* v24) {
-    sample_bits(stream_key(seed, pixel, node, light), s, u24, v24);
+                     uint32_t* u16, uint32_t* v16) {
+    sample_bits(stream_key(seed, pixel, node, light), s, u16, v16);
 }
 
 /* ---- scalar intersections ----------------------------------------------------- */
@@ -278,8 +278,8 @@ static double shadow_ratio(const scene_t* sc, ctx_t* cx, v3 hit, int li, uint32_
         for (int j = 0; j < N; ++j) {
             int s = i * N + j;
             uint32_t ub, vb; sample_bits(key, (uint32_t)s, &ub, &vb);
-            double u = (i + ub * (1.0 / 16777216.0)) / N;
-            double v = (j + vb * (1.0 / 16777216.0)) / N;
+            double u = (i + ub * (1.0 / 65536.0)) / N;
+            double v = (j + vb * (1.0 / 65536.0)) / N;
             u = u - 0.5; v = v - 0.5;
             v3 off = add(scl(right, u * lt->radius), scl(up, v * lt->radius));
             v3 smp = add(lt->pos, off);

@@ -318,6 +318,7 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
         return fail(h, RT_ERR_INVALID, "rt_scene_desc: bad struct_size / abi_version");
     if (d->n_surfaces < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(h, RT_ERR_INVALID, "negative count");
     if (d->n_surfaces >= (1 << 24)) return fail(h, RT_ERR_UNSUPPORTED, "more than 2^24-1 surfaces");
+    if (d->n_lights >= (1 << 24)) return fail(h, RT_ERR_UNSUPPORTED, "more than 2^24-1 lights");
     if (d->n_shadow < 1) return fail(h, RT_ERR_INVALID, "n_shadow must be >= 1");
     if (d->n_shadow > 1024) return fail(h, RT_ERR_UNSUPPORTED, "n_shadow above 1024");
     if (d->max_rec < 0 || d->max_rec > 31) return fail(h, RT_ERR_UNSUPPORTED, "max_rec must be in [0, 31] (32-bit ray-tree node ids)");
@@ -528,11 +529,11 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
     return RT_OK;
 }
 
-void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s, uint32_t* u24, uint32_t* v24) {
+void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s, uint32_t* u16, uint32_t* v16) {
     uint32_t u, v;
     rt_sample_bits(rt_grid_key(rt_seed_key(seed), pixel, node, light), s, u, v);
-    if (u24) *u24 = u;
-    if (v24) *v24 = v;
+    if (u16) *u16 = u;
+    if (v16) *v16 = v;
 }
 
 }  // extern "C"

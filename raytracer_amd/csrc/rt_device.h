@@ -121,8 +121,8 @@ __host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixe
 }
 __host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t s, uint32_t& u, uint32_t& v) {
     uint32_t m = rt_mix32(key + s * 0x9E3779B9u);
-    u = m >> 8;
-    v = ((m ^ 0x68E31DA4u) * 0x2C9277B5u) >> 8;
+    u = m >> 16;
+    v = m & 0xFFFFu;
 }
 
 // ---- launch wrappers implemented by the .hip files -------------------------------

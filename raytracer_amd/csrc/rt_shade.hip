@@ -202,8 +202,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                     for (int j = 0; j < N; ++j, ++s_idx) {
                         uint32_t ub, vb;
                         rt_sample_bits(key, s_idx, ub, vb);
-                        const float u = ((float)i + (float)ub * 5.9604644775390625e-08f) * invN - 0.5f;
-                        const float v = ((float)j + (float)vb * 5.9604644775390625e-08f) * invN - 0.5f;
+                        const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
+                        const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
                         const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
                         const float d2 = dot(sv, sv);
                         const float dinv = __frsqrt_rn(d2);
@@ -342,10 +342,9 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
             for (int j = j0; j < j1; ++j) {
                 const uint32_t mm = rt_mix32(ctr);
                 ctr += 0x9E3779B9u;
-                const uint32_t mv = (mm ^ 0x68E31DA4u) * 0x2C9277B5u;
-                // (i << 24) | (m >> 8): the cell index rides in the top byte of the 24-bit jitter
-                const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 8), ku, koff);
-                const float vr = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)j, mv, 8), ku, koff);
+                // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
+                const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 16), ku, koff);
+                const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
                 const float len = __builtin_amdgcn_sqrtf(fmaf(ur, ur, fmaf(vr, vr, lc2)));
                 float val[K];
 #pragma unroll
@@ -416,6 +415,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
         for (int l = 0; l < L; ++l) {
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
+            uint32_t defer_mask = defer ? 0xFFu : 0u;  // surfaces the generic loop has to test for this (wave, light)
             float ratio = 1.f;
             const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
             const float lc2 = dot(lrel, lrel);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
                 float A[NSLOT], B[NSLOT], C[NSLOT];
                 bool gen = false;
-                uint32_t lin = 0;
+                uint32_t lin = 0, reach_bits = 0;
 #pragma unroll
                 for (int j = 0; j < SMALL_MAX; ++j) {
                     A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
@@ -456,6 +456,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                             const float reach = r + rho * fminf(1.f, s_hi_scale * (r + t * llen));
                             const bool never = own || !lit || dot(q, q) > reach * reach * 1.0002f;
                             if (!never) {
+                                reach_bits |= 1u << j;
                                 const float lmin = llen - rho;
                                 const bool linear_ok = c >= 1e-3f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
                                 if (!linear_ok) gen = true;
@@ -473,6 +474,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                             const float dn0 = dot(lrel, n) * sg;  // > |h|  <=>  L is on the far side
                             const bool never = own || !lit || (ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0));
                             if (!never) {
+                                reach_bits |= 1u << j;
                                 if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho))) gen = true;
                                 else {
                                     A[j] = dn0 - ah; B[j] = dot(right, n) * sg; C[j] = dot(up, n) * sg;
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                                 const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
                                 const f3 q = oc + lrel * t;
                                 const float reach = sf.c.w + rho;
-                                if (!(dot(q, q) > reach * reach * 1.0002f)) gen = true;
+                                if (!(dot(q, q) > reach * reach * 1.0002f)) { gen = true; reach_bits |= 1u << j; }
                             }
                         }
                     }
@@ -511,6 +513,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                     if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
                 const int k = __popc(cand);
                 defer = __any(gen) || k > KMAX;
+                if (defer) {
+#pragma unroll
+                    for (int s = 0; s < SMALL_MAX; ++s)
+                        if (__ballot((reach_bits >> s) & 1u)) defer_mask |= 1u << s;
+                }
                 if (!defer) {
                     wl_n[k <= 4 ? k : 4] += 1;
                     if (k > 0) {
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
                             if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.transp;
                         }
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-                        const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
+                        const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
                         const float koff = -0.5f * lt.radius;
                         float sum;
                         switch (k) {
@@ -555,7 +562,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
             if (defer) {
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(a.deferred_count, 1u);
-                    a.deferred[slot] = make_uint2(base, (uint32_t)l);
+                    a.deferred[slot] = make_uint2(base, (uint32_t)l | (defer_mask << 24));
                 }
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
@@ -604,7 +611,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         if (item >= n_items) break;
         const uint2 it = a.deferred[item];
         const uint32_t base = __builtin_amdgcn_readfirstlane(it.x);
-        const int l = (int)__builtin_amdgcn_readfirstlane(it.y);
+        const int l = (int)(__builtin_amdgcn_readfirstlane(it.y) & 0xFFFFFFu);
+        const uint32_t smask = __builtin_amdgcn_readfirstlane(it.y) >> 24;  // surfaces in reach of some lane
         const uint32_t idx = base + lane;
         const bool active = idx < count;
         const HitRec h = load_hit(a.q, active ? idx : base);
@@ -674,7 +682,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const f3 right = normalize(cross(ldir, perp));
             const f3 up = normalize(cross(right, ldir));
             const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-            const float ku = 5.9604644775390625e-08f * invN * lt.radius;  // 2^-24 / N * radius
+            const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
             float sum = 0.f;
             uint32_t ctr = key;
             for (int i = 0; i < N; ++i) {
@@ -704,7 +712,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                     float f = 1.f;
 #pragma unroll
                     for (int s = 0; s < SMALL_MAX; ++s) {
-                        if (s < S) {
+                        if (s < S && ((smask >> s) & 1u)) {
                             bool blk;
                             if (STYPE(s) == RT_SURF_SPHERE) {
                                 const float b = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));

@@ -53,7 +53,7 @@ def assemble(tiles, height, width, world, stripe_rows, xp=np):
 class DistributedRenderer:
     """Per-rank renderer + preallocated device tiles + the gather."""
 
-    def __init__(self, renderer, width, height, group=None, stripe_rows=None):
+    def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0):
         import torch
         import torch.distributed as dist
 
@@ -63,6 +63,7 @@ class DistributedRenderer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.W, self.H = int(width), int(height)
+        self.flags = int(flags)
         self.stripe_rows = stripe_rows or stripe_rows_for(self.H, self.world)
         self.my_rows = rank_rows(self.H, self.world, self.rank, self.stripe_rows)
         self.max_rows = max_rows_per_rank(self.H, self.world, self.stripe_rows)
@@ -81,7 +82,8 @@ class DistributedRenderer:
         torch, dist = self.torch, self.dist
         stream = torch.cuda.current_stream(self.tile.device).cuda_stream
         stats = self.r.render_rows_device(self.W, self.H, 0, self.tile.data_ptr(), stream=stream, seed=seed,
-                                          stripe_rows=self.stripe_rows, stripe_count=self.world, stripe_index=self.rank)
+                                          stripe_rows=self.stripe_rows, stripe_count=self.world, stripe_index=self.rank,
+                                          flags=self.flags)
         if self.world == 1:
             return self.tile[: len(self.my_rows)], stats
         dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)

@@ -113,9 +113,9 @@ class Renderer:
         return self
 
     def render_rows(self, width, height, *, seed=0, row_begin=0, row_end=None, stripe_rows=1, stripe_count=1,
-                    stripe_index=0, want_f32=True, want_u8=True):
+                    stripe_index=0, want_f32=True, want_u8=True, flags=0):
         """Render the selected rows of a frame; returns ``(f32 or None, u8 or None, stats dict)``."""
-        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed)
+        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed, flags)
         rows = self._lib.rt_rows_selected(C.byref(p))
         f32 = np.empty((rows, int(width), 3), dtype=np.float32) if want_f32 else None
         u8 = np.empty((rows, int(width), 3), dtype=np.uint8) if want_u8 else None
@@ -125,9 +125,9 @@ class Renderer:
         return f32, u8, _stats_dict(st)
 
     def render_rows_device(self, width, height, dev_f32_ptr, dev_u8_ptr, *, stream=None, seed=0, row_begin=0,
-                           row_end=None, stripe_rows=1, stripe_count=1, stripe_index=0):
+                           row_end=None, stripe_rows=1, stripe_count=1, stripe_index=0, flags=0):
         """Render into DEVICE buffers (raw pointers, e.g. ``tensor.data_ptr()``); returns the stats dict."""
-        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed)
+        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed, flags)
         st = packing.RtStats()
         self._check(self._lib.rt_render_device(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None,
                                                stream or None, C.byref(st)))

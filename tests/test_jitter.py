@@ -8,16 +8,16 @@ from oracle import jitter
 def test_python_statement_matches_golden_table():
     for row in golden_json("kat/jitter_kat.json"):
         u, v = jitter.sample_bits(jitter.stream_key(row["seed"], row["pixel"], row["node"], row["light"]), row["s"])
-        assert (u, v) == (row["u24"], row["v24"])
-        assert 0 <= u < 1 << 24 and 0 <= v < 1 << 24
+        assert (u, v) == (row["u"], row["v"])
+        assert 0 <= u < 1 << 16 and 0 <= v < 1 << 16
 
 
-def test_uniform_is_24_bit_fraction():
+def test_uniform_is_16_bit_fraction():
     x = jitter.uniform(3, 1000, 5, 2, 7)
-    assert 0.0 <= x < 1.0 and (x * 16777216.0).is_integer()
+    assert 0.0 <= x < 1.0 and (x * 65536.0).is_integer()
     u, v = jitter.sample_bits(jitter.stream_key(3, 1000, 5, 2), 3)
-    assert jitter.uniform(3, 1000, 5, 2, 6) == u / 16777216.0   # even draw = u
-    assert jitter.uniform(3, 1000, 5, 2, 7) == v / 16777216.0   # odd draw = v
+    assert jitter.uniform(3, 1000, 5, 2, 6) == u / 65536.0   # even draw = u
+    assert jitter.uniform(3, 1000, 5, 2, 7) == v / 65536.0   # odd draw = v
 
 
 def test_oracle_c_matches_python(oracle):
