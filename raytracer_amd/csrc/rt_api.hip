@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,8 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
+constexpr size_t kMinArenaPixels = 65536;
+constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 
 }  // namespace
 
@@ -107,6 +110,7 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const int lights = h->L > 0 ? h->L : 1;
     if (pixels <= h->band_capacity && lights <= h->arena_lights) return RT_OK;
     if (pixels < h->band_capacity) pixels = h->band_capacity;
+    if (pixels < kMinArenaPixels) pixels = kMinArenaPixels;  // head-room for deep ray trees of small frames
     free_frame_buffers(h);
     const size_t rcap = pixels * kRayFactor, scap = pixels * kShadeFactor;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -250,8 +254,14 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
         if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
         if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) {
             if (n == 1) {
-                (void)hipEventDestroy(e_end);
-                return fail(h, RT_ERR_QUEUE, "ray tree of a single row exceeds the queue capacity");
+                // a single row outgrew the queues: enlarge them (the ray tree can double per level)
+                if (h->band_capacity * 2 > kMaxArenaPixels) {
+                    (void)hipEventDestroy(e_end);
+                    return fail(h, RT_ERR_QUEUE, "ray tree of a single row exceeds the largest queue capacity");
+                }
+                rc = ensure_band_capacity(h, h->band_capacity * 2);
+                if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+                continue;
             }
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
@@ -289,6 +299,10 @@ int rt_create(int device, rt_handle** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return RT_ERR_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
+        long v = std::atol(e);
+        if (v > 0) h->max_band_pixels = (size_t)v;
+    }
     bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess &&
               hipMalloc(&h->d_qcounts, sizeof(uint32_t) * 8) == hipSuccess;
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;

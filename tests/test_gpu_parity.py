@@ -236,3 +236,33 @@ def test_headline_frame_properties(renderer):
     _, b, _ = renderer.render_rows(w, h, seed=1, want_f32=False, row_begin=1000, row_end=1128)
     m = CI.metrics(a[1000:1128], b)
     assert m["psnr"] > 45.0   # N = 16: jitter noise is small
+
+
+def test_row_bands_and_queue_growth(oracle, tmp_path, monkeypatch):
+    """Frames larger than a band are rendered in row bands; a ray tree that outgrows the queues makes the
+    library retry with fewer rows and, at one row, with larger queues -- the image does not change."""
+    monkeypatch.setenv("RT_MAX_BAND_PIXELS", "2048")   # read by rt_create: bands of 2048 pixels
+    r = runtime.Renderer(0)
+    try:
+        sc = scene("transparency_v7")
+        r.set_scene(sc)
+        w, h = 160, 90
+        _, u8, st = r.render_rows(w, h, seed=2)
+        assert st["bands"] >= (w * h) // 2048
+        ref, cnt = oracle.render_frame(sc, w, h, seed=2, threads=THREADS)
+        assert_parity(u8, ref)
+        assert counters_of(st) == cnt
+        # binary ray tree: every hit spawns a reflection AND a transparency child, 12 levels deep
+        text = ("cam 0 0 6  0 0 0  0 1 0  1 1\nset 0.1 0.1 0.1 1 12\nmtl 0.5 0.5 0.5  1 1 1  0.5 0.5 0.5  10 0.5\n"
+                "sph 0 0 0 1 1\nsph 0 0 -3 1.5 1\nsph 2.2 0 0 1 1\nsph -2.2 0 0 1 1\npln 0 1 0 -1.2 1\npln 0 0 1 -6 1\n"
+                "lgt 3 4 5  1 1 1  1 0.5 1\n")
+        sc2 = R.parse_scene_file(write_scene(tmp_path, text))
+        r.set_scene(sc2)
+        w, h = 256, 8
+        _, u8, st = r.render_rows(w, h, seed=0)
+        ref, cnt = oracle.render_frame(sc2, w, h, seed=0, threads=THREADS)
+        assert cnt["secondary"] > 200 * w * h        # really a deep tree
+        assert counters_of(st) == cnt
+        assert_parity(u8, ref, bar=0.995)            # 2048 pixels
+    finally:
+        r.close()
