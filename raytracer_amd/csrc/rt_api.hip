@@ -40,6 +40,7 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
+constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 
 }  // namespace
@@ -174,7 +175,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     const size_t pixels = (size_t)n_rows * p->width;
     HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N, st));
-    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * 8, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * kQCounts, st));
     HIP_TRY(h, hipMemsetAsync(h->d_accum, 0, sizeof(double) * 3 * pixels, st));
 
     FrameParams fp{};
@@ -185,17 +186,17 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     fp.row_y = h->d_row_y;
 
     HIP_TRY(h, hipEventRecord(h->ev[0], st));
-    const int max_blocks = h->n_cu * 4;
+    const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
     for (int d = 0; d < depths; ++d) {
         TraceArgs ta{};
         ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat;
+        // every depth has its own counter word (zeroed with the others, once per band): no memset per depth
         ta.in = h->rq[d & 1]; ta.out = h->rq[(d + 1) & 1];
+        ta.in.count = h->d_qcounts + 8 + d; ta.out.count = h->d_qcounts + 8 + d + 1;
         ta.shade = h->sq;
         ta.dbg = debug ? h->dbg : HitDebug{};
         ta.accum = h->d_accum; ta.counters = h->d_counters; ta.depth = d;
-        // the queue this depth fills must start empty (it was the input two depths ago)
-        HIP_TRY(h, hipMemsetAsync(ta.out.count, 0, sizeof(uint32_t), st));
         int blocks = max_blocks;
         if (d == 0) blocks = (int)std::min<size_t>((pixels + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
@@ -208,6 +209,10 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
+        // one work item per 64-hit chunk.  Splitting a chunk's lights over several items was measured
+        // slower even on small bands: the items of one hit run concurrently and their float64
+        // accumulator updates collide on the same addresses.
+        sa.light_groups = 1;
         sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
         sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
@@ -304,7 +309,7 @@ int rt_create(int device, rt_handle** out) {
         if (v > 0) h->max_band_pixels = (size_t)v;
     }
     bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess &&
-              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * 8) == hipSuccess;
+              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * kQCounts) == hipSuccess;
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) { rt_destroy(h); return RT_ERR_DEVICE; }
     *out = h;

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
     const bool classify = !a.no_cull && N < 256;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
 
     // wave-uniform: 4 type bits per surface in one word
     uint32_t tword = 0;
@@ -388,18 +389,27 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
     // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
     // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
+    // work item = (64-hit chunk, light group): group g of G owns lights g, g+G, ...  The host picks
+    // G = 1 for big bands (one accumulator update per hit) and up to L for small ones, where the
+    // time of one item decides the tail of the launch
+    const uint32_t G = (uint32_t)a.light_groups;
+    const uint32_t n_items = ((count + 63u) >> 6) * G;
     uint32_t grab = 0, grab_end = 0;
     for (;;) {
         if (grab >= grab_end) {
+            // batches of 4 while plenty of work is left, single items towards the end
+            const uint32_t batch = (grab_end + 16u * n_waves < n_items) ? 4u : 1u;
             uint32_t g0 = 0;
-            if (lane == 0) g0 = atomicAdd(a.work, 256u);
+            if (lane == 0) g0 = atomicAdd(a.work, batch);
             grab = __builtin_amdgcn_readfirstlane(g0);
-            grab_end = grab + 256u;
-            if (grab >= count) break;
+            grab_end = grab + batch;
+            if (grab >= n_items) break;
         }
-        const uint32_t base = grab;
-        grab += 64u;
-        if (base >= count) { grab = grab_end; continue; }
+        const uint32_t item = grab;
+        grab += 1u;
+        if (item >= n_items) { grab = grab_end; continue; }
+        const uint32_t base = (item / G) << 6;
+        const int l_first = (int)(item % G);
         const uint32_t idx = base + lane;
         const bool active = idx < count;
         const HitRec h = load_hit(a.q, active ? idx : base);  // idle lanes shadow the chunk's first hit, results dropped
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
         const bool own_sph_blocks = own_sphere && !(h.flags & HF_CBATCH_POS);
 
         f3 color = F3(0.f, 0.f, 0.f);
-        for (int l = 0; l < L; ++l) {
+        for (int l = l_first; l < L; l += (int)G) {
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? 0xFFu : 0u;  // surfaces the generic loop has to test for this (wave, light)
