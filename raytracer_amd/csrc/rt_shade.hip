@@ -369,7 +369,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
 }
 
 template <bool ALL_OPAQUE>
-__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_fast(ShadeArgs a) {
+__global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
     uint32_t count = *a.q.count;
     if (count > a.q.capacity) count = a.q.capacity;
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -614,10 +614,18 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
     }
     tword = __builtin_amdgcn_readfirstlane(tword);
 
+    // One item per WORKGROUP: its four waves hold the same 64 hits and split the sample rows
+    // (wave w takes rows w, w+4, ...); partial sums meet in LDS.  Items are few and long, so the
+    // latency of one item decides how long this launch takes.
+    __shared__ uint32_t s_item;
+    __shared__ float s_sum[SHADE_BLOCK / 64][64];
+    const int wv = (int)(threadIdx.x >> 6);
+    constexpr int NWV = SHADE_BLOCK / 64;
     for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(a.work2, 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
+        if (threadIdx.x == 0) s_item = atomicAdd(a.work2, 1u);
+        __syncthreads();
+        const uint32_t item = s_item;
+        __syncthreads();
         if (item >= n_items) break;
         const uint2 it = a.deferred[item];
         const uint32_t base = __builtin_amdgcn_readfirstlane(it.x);
@@ -638,7 +646,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         const f3 ldir = lrel * linv;
         float ratio;
         if (lt.point_path) {
-            // ---- one ray to the light centre (ray_tracer.py:36-48), literal form
+            // ---- one ray to the light centre (ray_tracer.py:36-48), literal form (every wave computes it)
             const float dist = lc2 * linv;
             float f = 1.f;
             for (int s = 0; s < S; ++s) {
@@ -694,9 +702,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
             const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
             float sum = 0.f;
-            uint32_t ctr = key;
-            for (int i = 0; i < N; ++i) {
+            for (int i = wv; i < N; i += NWV) {
                 const float cu = ((float)i * invN - 0.5f) * lt.radius;
+                uint32_t ctr = key + (uint32_t)(i * N) * 0x9E3779B9u;
                 for (int j = 0; j < N; ++j) {
                     uint32_t ub, vb;
                     rt_sample_bits(ctr, 0u, ub, vb);
@@ -767,11 +775,17 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                     else sum += f;
                 }
             }
+            s_sum[wv][lane] = sum;
+            __syncthreads();
+            sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) sum += s_sum[w][lane];
+            __syncthreads();
             ratio = sum * inv_n2;
         }
         f3 color = F3(0.f, 0.f, 0.f);
         phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
-        if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
+        if (wv == 0 && active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
             const uint32_t lp = a.q.pixel[idx];
             unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
             unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
