@@ -116,8 +116,8 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const size_t rcap = pixels * kRayFactor, scap = pixels * kShadeFactor;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t bytes = 0;
-    bytes += 2 * (6 * al(rcap * 8) + 5 * al(rcap * 4));  // two ray queues
-    bytes += 16 * al(scap * 4);                         // shade queue
+    bytes += 2 * (4 * al(rcap * 16) + al(rcap * 4));     // two ray queues
+    bytes += 4 * al(scap * 16);                         // shade queue
     bytes += al(pixels * 3 * 8);                        // accumulators
     const size_t dcap = (scap / 64 + 1) * (size_t)lights; // every (64-hit chunk, light) pair at most once
     bytes += al(dcap * sizeof(uint2));
@@ -129,18 +129,14 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     auto take = [&](size_t b) { void* r = p; p += al(b); return r; };
     for (int q = 0; q < 2; ++q) {
         RayQueue& r = h->rq[q];
-        r.ox = (double*)take(rcap * 8); r.oy = (double*)take(rcap * 8); r.oz = (double*)take(rcap * 8);
-        r.dx = (double*)take(rcap * 8); r.dy = (double*)take(rcap * 8); r.dz = (double*)take(rcap * 8);
-        r.tr = (float*)take(rcap * 4); r.tg = (float*)take(rcap * 4); r.tb = (float*)take(rcap * 4);
-        r.pixel = (uint32_t*)take(rcap * 4); r.node = (uint32_t*)take(rcap * 4);
+        r.oa = (double2*)take(rcap * 16); r.ob = (double2*)take(rcap * 16); r.oc = (double2*)take(rcap * 16);
+        r.tp = (uint4*)take(rcap * 16); r.node = (uint32_t*)take(rcap * 4);
         r.count = h->d_qcounts + q;
         r.capacity = (uint32_t)rcap;
     }
     ShadeQueue& s = h->sq;
-    float** fp[12] = {&s.px, &s.py, &s.pz, &s.nx, &s.ny, &s.nz, &s.vx, &s.vy, &s.vz, &s.wr, &s.wg, &s.wb};
-    for (auto f : fp) *f = (float*)take(scap * 4);
-    s.pixel = (uint32_t*)take(scap * 4); s.gpixel = (uint32_t*)take(scap * 4);
-    s.node = (uint32_t*)take(scap * 4); s.meta = (uint32_t*)take(scap * 4);
+    s.r0 = (float4*)take(scap * 16); s.r1 = (float4*)take(scap * 16); s.r2 = (float4*)take(scap * 16);
+    s.r3 = (uint4*)take(scap * 16);
     s.count = h->d_qcounts + 2;
     s.capacity = (uint32_t)scap;
     h->d_accum = (double*)take(pixels * 3 * 8);
@@ -196,7 +192,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         ta.in.count = h->d_qcounts + 8 + d; ta.out.count = h->d_qcounts + 8 + d + 1;
         ta.shade = h->sq;
         ta.dbg = debug ? h->dbg : HitDebug{};
-        ta.accum = h->d_accum; ta.counters = h->d_counters; ta.depth = d;
+        ta.accum = h->d_accum; ta.npix = pixels; ta.counters = h->d_counters; ta.depth = d;
         int blocks = max_blocks;
         if (d == 0) blocks = (int)std::min<size_t>((pixels + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
@@ -205,7 +201,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     if (!debug) {
         ShadeArgs sa{};
         sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq;
-        sa.accum = h->d_accum; sa.counters = h->d_counters;
+        sa.accum = h->d_accum; sa.npix = pixels; sa.counters = h->d_counters;
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;

@@ -52,12 +52,12 @@ struct CameraD {
 };
 
 // ---- queues (structure of arrays in HBM; one slot per ray / per shaded hit) -----
+// Every array holds one 16-byte element per slot, so a wave reads / writes 1 KiB per instruction.
 struct RayQueue {
-    double *ox, *oy, *oz, *dx, *dy, *dz;  // float64 origin / direction (the bit-faithful chain)
-    float *tr, *tg, *tb;                  // throughput: product of kr / transparency up the tree
-    uint32_t *pixel;                      // LOCAL pixel index inside the band
-    uint32_t *node;                       // ray-tree node id (1 = camera ray, 2k reflect, 2k+1 transmit)
-    uint32_t* count;                      // device counter
+    double2 *oa, *ob, *oc;  // (ox,oy) (oz,dx) (dy,dz): float64 origin / direction (the bit-faithful chain)
+    uint4 *tp;              // throughput r,g,b (float bits: product of kr / transparency up the tree), LOCAL pixel index
+    uint32_t *node;         // ray-tree node id (1 = camera ray, 2k reflect, 2k+1 transmit)
+    uint32_t* count;        // device counter
     uint32_t capacity;
 };
 
@@ -69,14 +69,10 @@ struct RayQueue {
 #define HF_NO_OWN 8u       // degenerate hit (zero normal): no own-surface rule
 
 struct ShadeQueue {
-    float *px, *py, *pz;   // hit point
-    float *nx, *ny, *nz;   // stored (outward) normal
-    float *vx, *vy, *vz;   // view direction (towards the ray origin)
-    float *wr, *wg, *wb;   // weight = throughput * (1 - transparency)
-    uint32_t *pixel;       // LOCAL pixel index inside the band
-    uint32_t *gpixel;      // GLOBAL pixel index y*W+x (jitter key)
-    uint32_t *node;
-    uint32_t *meta;        // surface index | flags << 24
+    float4 *r0;   // hit point xyz, normal x
+    float4 *r1;   // normal yz (stored outward normal), view xy (direction towards the ray origin)
+    float4 *r2;   // view z, weight rgb = throughput * (1 - transparency)
+    uint4 *r3;    // LOCAL pixel index inside the band, GLOBAL pixel index y*W+x (jitter key), node, surface | flags << 24
     uint32_t* count;
     uint32_t capacity;
 };
@@ -134,7 +130,8 @@ struct TraceArgs {
     RayQueue in, out;
     ShadeQueue shade;
     HitDebug dbg;          // capacity 0 = off
-    double* accum;         // 3 per band pixel
+    double* accum;         // planar [3][npix]
+    size_t npix;           // pixels of the band
     unsigned long long* counters;
     int depth;
 };
@@ -156,7 +153,8 @@ struct ShadeArgs {
     const MatF* mat;
     const LightF* light;
     ShadeQueue q;
-    double* accum;
+    double* accum;       // planar [3][npix]
+    size_t npix;
     unsigned long long* counters;
 };
 void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s);

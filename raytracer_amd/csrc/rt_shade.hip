@@ -146,6 +146,26 @@ __device__ __forceinline__ bool box_blocks_a(const SurfF& s, f3 P, f3 w, float d
 
 __device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
+struct HitRec {
+    f3 P, nrm, view, wgt;
+    uint32_t lpix, gpix, node, flags;
+    int own_id;
+};
+
+__device__ __forceinline__ HitRec load_hit(const ShadeQueue& q, uint32_t li) {
+    const float4 a0 = q.r0[li], a1 = q.r1[li], a2 = q.r2[li];
+    const uint4 a3 = q.r3[li];
+    HitRec h;
+    h.P = F3(a0.x, a0.y, a0.z);
+    h.nrm = F3(a0.w, a1.x, a1.y);
+    h.view = F3(a1.z, a1.w, a2.x);
+    h.wgt = F3(a2.y, a2.z, a2.w);
+    h.lpix = a3.x; h.gpix = a3.y; h.node = a3.z;
+    h.flags = a3.w >> 24;
+    h.own_id = (int)(a3.w & 0xFFFFFFu);
+    return h;
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     uint32_t count = *a.q.count;
     if (count > a.q.capacity) count = a.q.capacity;
@@ -160,12 +180,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         const uint32_t idx = base + lane;
         const bool active = idx < count;
         const uint32_t li = active ? idx : base;  // idle lanes shadow item 0 of the chunk, results dropped
-        const f3 P = F3(a.q.px[li], a.q.py[li], a.q.pz[li]);
-        const f3 nrm = F3(a.q.nx[li], a.q.ny[li], a.q.nz[li]);
-        const f3 view = F3(a.q.vx[li], a.q.vy[li], a.q.vz[li]);
-        const uint32_t gpix = a.q.gpixel[li], node = a.q.node[li], meta = a.q.meta[li];
-        const int own_id = (meta >> 24) & HF_NO_OWN ? -1 : (int)(meta & 0xFFFFFFu);
-        const uint32_t flags = meta >> 24;
+        const HitRec hr = load_hit(a.q, li);
+        const f3 P = hr.P, nrm = hr.nrm, view = hr.view;
+        const uint32_t gpix = hr.gpix, node = hr.node, flags = hr.flags;
+        const uint32_t meta = (uint32_t)hr.own_id;
+        const int own_id = (flags & HF_NO_OWN) ? -1 : hr.own_id;
         const MatF m = a.mat[a.surf[meta & 0xFFFFFFu].mat];
 
         f3 color = F3(0.f, 0.f, 0.f);
@@ -239,10 +258,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             }
         }
         if (active) {
-            const uint32_t lp = a.q.pixel[idx];
-            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+            const uint32_t lp = hr.lpix;
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(hr.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(hr.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(hr.wgt.z * color.z));
         }
     }
 }
@@ -288,24 +307,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 #define SMALL_MAX 8
 #define NSLOT (SMALL_MAX + 1)  // + one slot for the hit's own sphere
 #define KMAX 8                 // linear tests the compact sample loop keeps in registers
-
-struct HitRec {
-    f3 P, nrm, view;
-    uint32_t gpix, node, flags;
-    int own_id;
-};
-
-__device__ __forceinline__ HitRec load_hit(const ShadeQueue& q, uint32_t li) {
-    HitRec h;
-    h.P = F3(q.px[li], q.py[li], q.pz[li]);
-    h.nrm = F3(q.nx[li], q.ny[li], q.nz[li]);
-    h.view = F3(q.vx[li], q.vy[li], q.vz[li]);
-    h.gpix = q.gpixel[li]; h.node = q.node[li];
-    const uint32_t meta = q.meta[li];
-    h.flags = meta >> 24;
-    h.own_id = (int)(meta & 0xFFFFFFu);
-    return h;
-}
 
 // intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light
 __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio) {
@@ -632,10 +633,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
             }
         }
         if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
-            const uint32_t lp = a.q.pixel[idx];
-            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+            const uint32_t lp = h.lpix;
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(h.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(h.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(h.wgt.z * color.z));
         }
     }
     if (lane == 0) {
@@ -838,10 +839,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         f3 color = F3(0.f, 0.f, 0.f);
         phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
         if (wv == 0 && active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
-            const uint32_t lp = a.q.pixel[idx];
-            unsafeAtomicAdd(&a.accum[lp * 3 + 0], (double)(a.q.wr[idx] * color.x));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 1], (double)(a.q.wg[idx] * color.y));
-            unsafeAtomicAdd(&a.accum[lp * 3 + 2], (double)(a.q.wb[idx] * color.z));
+            const uint32_t lp = h.lpix;
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(h.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(h.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(h.wgt.z * color.z));
         }
     }
 }
@@ -867,11 +868,14 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
 // resolve: clip(colour, 0, 1) * 255 (ray_tracer.py:330-331) -> float32 image and its
 // uint8 truncation (np.uint8, ray_tracer.py:438)
 // ---------------------------------------------------------------------------------------
+// accum is planar ([3][npix]: a wave's accumulator updates of one channel then touch neighbouring
+// addresses); the images are interleaved RGB
 __global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ accum, int64_t n, float* out_f32, uint8_t* out_u8) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    const int64_t npix = n / 3;
     for (; i < n; i += stride) {
-        double c = accum[i];
+        double c = accum[(i % 3) * npix + i / 3];
         c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
         float v = (float)(c * 255.0);
         if (out_f32) out_f32[i] = v;

@@ -168,10 +168,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                 d = normalize(sub(pt, cp));
                 o = cp;
             } else {
-                o = D3(a.in.ox[idx], a.in.oy[idx], a.in.oz[idx]);
-                d = D3(a.in.dx[idx], a.in.dy[idx], a.in.dz[idx]);
-                tr = a.in.tr[idx]; tg = a.in.tg[idx]; tb = a.in.tb[idx];
-                lpix = a.in.pixel[idx]; node = a.in.node[idx];
+                const double2 qa = a.in.oa[idx], qb = a.in.ob[idx], qc = a.in.oc[idx];
+                const uint4 qt = a.in.tp[idx];
+                o = D3(qa.x, qa.y, qb.x);
+                d = D3(qb.y, qc.x, qc.y);
+                tr = __uint_as_float(qt.x); tg = __uint_as_float(qt.y); tb = __uint_as_float(qt.z);
+                lpix = qt.w; node = a.in.node[idx];
                 int r = (int)(lpix / (uint32_t)W), px = (int)(lpix % (uint32_t)W);
                 gpix = (uint32_t)a.fp.row_y[r] * (uint32_t)W + (uint32_t)px;
             }
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
             // depth 0 >= max_recursions: every pixel is the background, nothing is traced (ray_tracer.py:261)
             if (active) {
                 n_traced -= 1; n_cut += 1;
-                a.accum[lpix * 3 + 0] = a.fp.bg[0]; a.accum[lpix * 3 + 1] = a.fp.bg[1]; a.accum[lpix * 3 + 2] = a.fp.bg[2];
+                a.accum[(size_t)0 * a.npix + lpix] = a.fp.bg[0]; a.accum[(size_t)1 * a.npix + lpix] = a.fp.bg[1]; a.accum[(size_t)2 * a.npix + lpix] = a.fp.bg[2];
             }
             continue;
         }
@@ -254,9 +256,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 
         // ---- ray left the scene: throughput * background (ray_tracer.py:269-270) ----------
         if (active && !hit) {
-            unsafeAtomicAdd(&a.accum[lpix * 3 + 0], (double)(tr * a.fp.bg[0]));
-            unsafeAtomicAdd(&a.accum[lpix * 3 + 1], (double)(tg * a.fp.bg[1]));
-            unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(tb * a.fp.bg[2]));
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(tr * a.fp.bg[0]));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(tg * a.fp.bg[1]));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(tb * a.fp.bg[2]));
         }
 
         // ---- reserve queue slots: ONE atomic per workgroup and queue ------------------------------
@@ -290,12 +292,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                 const uint32_t slot = slot_s;
                 d3 view = normalize(sub(o, P));  // ray_tracer.py:275
                 float om = (float)(1.0 - (double)m.transp);  // material.py:28
-                a.shade.px[slot] = (float)P.x; a.shade.py[slot] = (float)P.y; a.shade.pz[slot] = (float)P.z;
-                a.shade.nx[slot] = (float)n.x; a.shade.ny[slot] = (float)n.y; a.shade.nz[slot] = (float)n.z;
-                a.shade.vx[slot] = (float)view.x; a.shade.vy[slot] = (float)view.y; a.shade.vz[slot] = (float)view.z;
-                a.shade.wr[slot] = tr * om; a.shade.wg[slot] = tg * om; a.shade.wb[slot] = tb * om;
-                a.shade.pixel[slot] = lpix; a.shade.gpixel[slot] = gpix; a.shade.node[slot] = node;
-                a.shade.meta[slot] = (uint32_t)bs | (flags << 24);
+                a.shade.r0[slot] = make_float4((float)P.x, (float)P.y, (float)P.z, (float)n.x);
+                a.shade.r1[slot] = make_float4((float)n.y, (float)n.z, (float)view.x, (float)view.y);
+                a.shade.r2[slot] = make_float4((float)view.z, tr * om, tg * om, tb * om);
+                a.shade.r3[slot] = make_uint4(lpix, gpix, node, (uint32_t)bs | (flags << 24));
                 n_shaded += 1;
             } else ovf_shade += 1;
         }
@@ -304,9 +304,9 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         {
             const float cr = tr * m.kr[0], cg = tg * m.kr[1], cb = tb * m.kr[2];
             if (want_r && child_cut) {  // depth limit: the child returns the background untraced (:261-262)
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 0], (double)(cr * a.fp.bg[0]));
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 1], (double)(cg * a.fp.bg[1]));
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(cb * a.fp.bg[2]));
+                unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(cr * a.fp.bg[0]));
+                unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(cg * a.fp.bg[1]));
+                unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(cb * a.fp.bg[2]));
                 n_cut += 1;
             }
             if (push_r) {
@@ -314,10 +314,10 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                     const uint32_t slot = slot_r;
                     d3 rd = sub(d, scl(n, 2 * dotb(d, n)));  // ray_tracer.py:126
                     d3 ro = add(P, scl(n, RT_EPS));          // ray_tracer.py:198
-                    a.out.ox[slot] = ro.x; a.out.oy[slot] = ro.y; a.out.oz[slot] = ro.z;
-                    a.out.dx[slot] = rd.x; a.out.dy[slot] = rd.y; a.out.dz[slot] = rd.z;
-                    a.out.tr[slot] = cr; a.out.tg[slot] = cg; a.out.tb[slot] = cb;
-                    a.out.pixel[slot] = lpix; a.out.node[slot] = node * 2u;
+                    a.out.oa[slot] = make_double2(ro.x, ro.y); a.out.ob[slot] = make_double2(ro.z, rd.x);
+                    a.out.oc[slot] = make_double2(rd.y, rd.z);
+                    a.out.tp[slot] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), lpix);
+                    a.out.node[slot] = node * 2u;
                 } else ovf_ray += 1;
             }
         }
@@ -325,19 +325,19 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         {
             const float cr = tr * m.transp, cg = tg * m.transp, cb = tb * m.transp;
             if (want_t && child_cut) {
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 0], (double)(cr * a.fp.bg[0]));
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 1], (double)(cg * a.fp.bg[1]));
-                unsafeAtomicAdd(&a.accum[lpix * 3 + 2], (double)(cb * a.fp.bg[2]));
+                unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(cr * a.fp.bg[0]));
+                unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(cg * a.fp.bg[1]));
+                unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(cb * a.fp.bg[2]));
                 n_cut += 1;
             }
             if (push_t) {
                 if (slot_t < a.out.capacity) {
                     const uint32_t slot = slot_t;
                     d3 to = add(P, scl(d, RT_EPS));  // ray_tracer.py:230
-                    a.out.ox[slot] = to.x; a.out.oy[slot] = to.y; a.out.oz[slot] = to.z;
-                    a.out.dx[slot] = d.x; a.out.dy[slot] = d.y; a.out.dz[slot] = d.z;
-                    a.out.tr[slot] = cr; a.out.tg[slot] = cg; a.out.tb[slot] = cb;
-                    a.out.pixel[slot] = lpix; a.out.node[slot] = node * 2u + 1u;
+                    a.out.oa[slot] = make_double2(to.x, to.y); a.out.ob[slot] = make_double2(to.z, d.x);
+                    a.out.oc[slot] = make_double2(d.y, d.z);
+                    a.out.tp[slot] = make_uint4(__float_as_uint(cr), __float_as_uint(cg), __float_as_uint(cb), lpix);
+                    a.out.node[slot] = node * 2u + 1u;
                 } else ovf_ray += 1;
             }
         }
