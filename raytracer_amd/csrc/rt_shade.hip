@@ -307,6 +307,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 #define SMALL_MAX 8
 #define NSLOT (SMALL_MAX + 1)  // + one slot for the hit's own sphere
 #define KMAX 8                 // linear tests the compact sample loop keeps in registers
+#define PLANE_SCALE 1152921504606846976.0f  // 2^60
 
 // intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light
 __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio) {
@@ -325,17 +326,18 @@ __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, c
 }
 
 // N x N jittered samples of one light against K compacted linear tests.  Entry e blocks the
-// sample iff  A + ur*B + vr*C - len*tm >= 0  (tm = 1: tangent cone of a sphere, tm = 0: plane
-// crossing); tm / tr are wave-uniform.  All-opaque scenes only need "any entry blocks" =
-// sign of the maximum, shifted into a bit mask and counted once per row.
+// sample iff  lin_e = A + ur*B + vr*C >= len  (tangent cone of a sphere; a plane crossing
+// "lin >= 0" is brought to the same form by scaling its row with PLANE_SCALE, which moves its
+// threshold from 0 to len * 2^-60).  lin >= len  <=>  lin*|lin| - len^2 >= 0, so no square
+// root is taken.  All-opaque scenes only need "any entry blocks" = that sign for the maximum
+// of the lin_e, shifted into a bit mask and counted once per row.
 // Returns the sum of the light factors of the N*N samples.
 template <int K, bool ALL_OPAQUE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
-                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tm)[KMAX],
-                                                 const float (&tr)[KMAX]) {
+                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX]) {
     if (ALL_OPAQUE) {
         // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
-        // Every entry is affine in (ur, vr) minus tm*len, so its range over a tile's rectangle follows
+        // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
         // from the corners; when, for every lane of the wave, either no entry can block anywhere in
         // the tile or one entry blocks everywhere, the tile's samples are not generated at all (the
         // jitter stream is keyed by the sample index, so skipping samples does not shift the others).
@@ -354,8 +356,8 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
 #pragma unroll
             for (int e = 0; e < K; ++e) {
                 const float bu0 = ua * Bd[e], bu1 = ub * Bd[e], cv0 = va * Cd[e], cv1 = vb * Cd[e];
-                const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - tm[e] * len_lo;
-                const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - tm[e] * len_hi;
+                const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
+                const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
                 const float margin = 1e-5f * (fabsf(Ad[e]) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
                 can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
                 must_block = must_block || lo > margin;
@@ -383,13 +385,13 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                                 // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
                                 const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 16), ku, koff);
                                 const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
-                                const float len = __builtin_amdgcn_sqrtf(fmaf(ur, ur, fmaf(vr, vr, lc2)));
-                                float vmax = fmaf(-len, tm[0], fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0])));
+                                const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
+                                float vmax = fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0]));
 #pragma unroll
                                 for (int e = 1; e < K; ++e)
-                                    vmax = __builtin_fmaxf(vmax, fmaf(-len, tm[e], fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]))));
+                                    vmax = __builtin_fmaxf(vmax, fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e])));
                                 // sign bit set <=> no entry blocks this sample
-                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(vmax), 31);
+                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(vmax, fabsf(vmax), -len2)), 31);
                             }
                             open_samples += (uint32_t)__popc(mask);
                         }
@@ -407,12 +409,12 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                 ctr += 0x9E3779B9u;
                 const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 16), ku, koff);
                 const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
-                const float len = __builtin_amdgcn_sqrtf(fmaf(ur, ur, fmaf(vr, vr, lc2)));
+                const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
                 float f = 1.f;
 #pragma unroll
                 for (int e = 0; e < K; ++e) {
-                    const float val = fmaf(-len, tm[e], fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e])));
-                    f = val >= 0.f ? f * tr[e] : f;
+                    const float lin = fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]));
+                    f = fmaf(lin, fabsf(lin), -len2) >= 0.f ? f * tr[e] : f;
                 }
                 sum += f;
             }
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                                 reach_bits |= 1u << j;
                                 if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho))) gen = true;
                                 else {
-                                    A[j] = dn0 - ah; B[j] = dot(right, n) * sg; C[j] = dot(up, n) * sg;
+                                    A[j] = (dn0 - ah) * PLANE_SCALE; B[j] = dot(right, n) * (sg * PLANE_SCALE); C[j] = dot(up, n) * (sg * PLANE_SCALE);
                                     lin |= 1u << j;
                                 }
                             }
@@ -585,21 +587,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                     wl_n[k <= 4 ? k : 4] += 1;
                     if (k > 0) {
                         // ---- compact the wave's candidate tests into register triples
-                        float Ad[KMAX], Bd[KMAX], Cd[KMAX], tmd[KMAX], trd[KMAX];
+                        float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
                         uint32_t rem = cand;
 #pragma unroll
                         for (int e = 0; e < KMAX; ++e) {
                             const int sl = rem ? (int)__builtin_ctz(rem) : -1;
                             rem &= rem - 1u;
-                            Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; tmd[e] = 1.f; trd[e] = 1.f;
+                            Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
 #pragma unroll
                             for (int t = 0; t < NSLOT; ++t) {
                                 if (sl == t) {
                                     Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t];
-                                    if (t < SMALL_MAX) {
-                                        tmd[e] = STYPE(t < SMALL_MAX ? t : 0) == RT_SURF_PLANE ? 0.f : 1.f;
-                                        if (!ALL_OPAQUE) trd[e] = a.surf[t < SMALL_MAX ? t : 0].transp;
-                                    }
+                                    if (!ALL_OPAQUE && t < SMALL_MAX) trd[e] = a.surf[t < SMALL_MAX ? t : 0].transp;
                                 }
                             }
                             if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.transp;
@@ -609,14 +608,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                         const float koff = -0.5f * lt.radius;
                         float sum;
                         switch (k) {
-                            case 1: sum = compact_samples<1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 2: sum = compact_samples<2, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 3: sum = compact_samples<3, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 4: sum = compact_samples<4, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 5: sum = compact_samples<5, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 6: sum = compact_samples<6, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            case 7: sum = compact_samples<7, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
-                            default: sum = compact_samples<8, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, tmd, trd); break;
+                            case 1: sum = compact_samples<1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 2: sum = compact_samples<2, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 3: sum = compact_samples<3, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 4: sum = compact_samples<4, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 5: sum = compact_samples<5, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 6: sum = compact_samples<6, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            case 7: sum = compact_samples<7, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                            default: sum = compact_samples<8, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
                         }
                         ratio = sum * inv_n2;
                     }
