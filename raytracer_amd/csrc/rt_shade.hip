@@ -379,11 +379,12 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                         for (int i = i0; i < i1; ++i) {
                             uint32_t ctr = key + (uint32_t)(i * N + j0) * 0x9E3779B9u;
                             uint32_t mask = 0;
+                            const float urow = fmaf((float)i, cell, koff);  // left edge of row i
                             for (int j = j0; j < j1; ++j) {
                                 const uint32_t mm = rt_mix32(ctr);
                                 ctr += 0x9E3779B9u;
+                                const float ur = fmaf((float)(mm >> 16), ku, urow);
                                 // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
-                                const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 16), ku, koff);
                                 const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
                                 const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
                                 float vmax = fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0]));
