@@ -40,6 +40,11 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
+// A level with fewer rays than this per CU goes to the run-to-completion kernel.  Measured on the 4K pool frame
+// (2.2 M rays at depth 1, 1.0 M at depth 2): starting the tail at depth 2 is fastest there, at depth 1 for an
+// eighth of the frame; an earlier start saves queue traffic and launches but orders the shade queue less
+// coherently, which costs more in the shading kernel than it saves here.
+constexpr double kTailRaysPerCu = 6144.0;
 constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 
@@ -72,8 +77,18 @@ struct rt_handle {
     ShadeQueue sq{};
     HitDebug dbg{};
     double* d_accum = nullptr;
-    unsigned long long* d_counters = nullptr;
+    unsigned long long* d_counters = nullptr;  // CNT_N statistics words, directly followed by d_qcounts (one memset per band)
     uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
+    // run-to-completion tail of the ray tree (k_trace_tail)
+    bool both_children = false;      // some material spawns a reflection and a transparency child
+    RayQueue stack{};                // parked children, [level][thread]
+    void* stack_mem = nullptr;
+    size_t stack_slots = 0;
+    int tail_override = -1;          // RT_TAIL_FROM: -1 automatic, 0 never, d >= 1 always from depth d, -2 camera rays too
+    bool have_history = false;       // depth_ratio holds the previous band's rays per pixel at each depth
+    double depth_ratio[32] = {};
+    size_t accum_zero_prefix = 0;    // accumulator values [0, prefix) are known to be zero (k_resolve clears what it reads)
+    std::vector<int32_t> rows_on_device;  // what d_row_y holds
     uint2* d_deferred = nullptr;
     int arena_lights = 0;
     int32_t* d_row_y = nullptr;
@@ -104,6 +119,7 @@ void free_frame_buffers(rt_handle* h) {
     h->arena = nullptr;
     h->band_capacity = 0;
     h->arena_lights = 0;
+    h->accum_zero_prefix = 0;
 }
 
 // carve the SoA queues out of one arena
@@ -163,16 +179,57 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
         if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) rows.push_back(y);
 }
 
-struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
+// c and q mirror the device block: statistics words, then the queue counter words
+struct BandResult { unsigned long long c[CNT_N]; uint32_t q[kQCounts]; float ms_trace, ms_shade, ms_resolve; int tail_from; };
+
+// Depth from which one k_trace_tail launch replaces the per-level launches (>= depths: never).
+// Automatic mode uses the rays per pixel the previous band of this scene had at each depth (depth 2
+// before any band has run).  The choice never changes the image.
+int choose_tail_depth(const rt_handle* h, int depths, size_t pixels) {
+    if (h->S > RT_SURF_TILE || depths < 2) return depths;
+    if (h->tail_override == -2) return 0;  // the camera rays as well: one launch for the whole tree
+    if (h->tail_override == 0) return depths;
+    if (h->tail_override > 0) return std::min(h->tail_override, depths);
+    if (!h->have_history) return std::min(2, depths);
+    const double limit = (double)h->n_cu * kTailRaysPerCu;
+    for (int d = 1; d < depths; ++d)
+        if (h->depth_ratio[d] * (double)pixels <= limit) return d;
+    return depths;
+}
+
+int ensure_tail_stack(rt_handle* h, int blocks) {
+    if (!h->both_children) return RT_OK;  // no hit can park a child: the kernel gets stack_levels = 0
+    const size_t threads = (size_t)blocks * RT_TAIL_BLOCK, slots = threads * (size_t)std::max(h->R, 1);
+    if (slots <= h->stack_slots) return RT_OK;
+    if (h->stack_mem) (void)hipFree(h->stack_mem);
+    h->stack_mem = nullptr; h->stack_slots = 0;
+    HIP_TRY(h, hipMalloc(&h->stack_mem, slots * 68));
+    char* p = (char*)h->stack_mem;
+    h->stack.oa = (double2*)p; p += slots * 16;
+    h->stack.ob = (double2*)p; p += slots * 16;
+    h->stack.oc = (double2*)p; p += slots * 16;
+    h->stack.tp = (uint4*)p; p += slots * 16;
+    h->stack.node = (uint32_t*)p;
+    h->stack.count = nullptr; h->stack.capacity = (uint32_t)std::min<size_t>(slots, 0xFFFFFFFFu);
+    h->stack_slots = slots;
+    return RT_OK;
+}
 
 // enqueue one band; rows[r0..r1) ; outputs are device pointers to the band's first value (may be null)
 int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n_rows, float* d_f32, uint8_t* d_u8,
              hipStream_t st, bool debug, BandResult* res) {
     const size_t pixels = (size_t)n_rows * p->width;
-    HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
-    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N, st));
-    HIP_TRY(h, hipMemsetAsync(h->d_qcounts, 0, sizeof(uint32_t) * kQCounts, st));
-    HIP_TRY(h, hipMemsetAsync(h->d_accum, 0, sizeof(double) * 3 * pixels, st));
+    if (h->rows_on_device.size() != (size_t)n_rows || std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) {
+        h->rows_on_device.clear();  // stays empty if the copy fails
+        HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
+        h->rows_on_device.assign(rows, rows + n_rows);
+    }
+    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts, st));
+    if (h->accum_zero_prefix < 3 * pixels) {
+        HIP_TRY(h, hipMemsetAsync(h->d_accum + h->accum_zero_prefix, 0, sizeof(double) * (3 * pixels - h->accum_zero_prefix), st));
+    }
+    const size_t zero_before = std::max(h->accum_zero_prefix, 3 * pixels);
+    h->accum_zero_prefix = 0;  // dirty until k_resolve has run over this band
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.band_rows = n_rows;
@@ -184,7 +241,11 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventRecord(h->ev[0], st));
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
-    for (int d = 0; d < depths; ++d) {
+    const int tail_from = choose_tail_depth(h, depths, pixels);
+    const int tail_blocks = h->n_cu * 2;
+    if (tail_from < depths) { int rc = ensure_tail_stack(h, tail_blocks); if (rc != RT_OK) return rc; }
+    res->tail_from = tail_from;
+    for (int d = 0; d < depths && d <= tail_from; ++d) {
         TraceArgs ta{};
         ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat;
         // every depth has its own counter word (zeroed with the others, once per band): no memset per depth
@@ -193,6 +254,11 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         ta.shade = h->sq;
         ta.dbg = debug ? h->dbg : HitDebug{};
         ta.accum = h->d_accum; ta.npix = pixels; ta.counters = h->d_counters; ta.depth = d;
+        if (d == tail_from) {
+            ta.stack = h->stack; ta.stack_levels = h->both_children ? (uint32_t)h->R : 0u;
+            rt_launch_trace_tail(ta, tail_blocks, st);
+            break;
+        }
         int blocks = max_blocks;
         if (d == 0) blocks = (int)std::min<size_t>((pixels + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
@@ -214,14 +280,16 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[2], st));
-    if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels * 3, d_f32, d_u8, st);
+    if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels, d_f32, d_u8, st);
     HIP_TRY(h, hipEventRecord(h->ev[3], st));
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    static_assert(offsetof(BandResult, q) == sizeof(unsigned long long) * CNT_N, "BandResult mirrors the device counter block");
+    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c) + sizeof(res->q), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, h->ev[0], h->ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, h->ev[1], h->ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, h->ev[2], h->ev[3]));
+    if (!debug && (d_f32 || d_u8)) h->accum_zero_prefix = zero_before;
     return RT_OK;
 }
 
@@ -233,7 +301,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     if (rows.empty()) { if (stats) *stats = s; return RT_OK; }
     if (rows.size() > h->row_y_cap) {
         if (h->d_row_y) (void)hipFree(h->d_row_y);
-        h->d_row_y = nullptr; h->row_y_cap = 0;
+        h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
         HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
         h->row_y_cap = rows.size();
     }
@@ -267,6 +335,9 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
         }
+        // rays per pixel at every depth that still had a launch of its own (deeper ones keep their last value)
+        for (int d = 1; d < 32 && d < h->R && d <= br.tail_from; ++d) h->depth_ratio[d] = (double)br.q[8 + d] / (double)(n * W);
+        h->have_history = true;
         s.primary_rays += br.c[CNT_PRIMARY]; s.secondary_rays += br.c[CNT_SECONDARY];
         s.depth_cut += br.c[CNT_DEPTH_CUT]; s.shaded_points += br.c[CNT_SHADED];
         s.ms_trace += br.ms_trace; s.ms_shade += br.ms_shade; s.ms_resolve += br.ms_resolve;
@@ -300,12 +371,14 @@ int rt_create(int device, rt_handle** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return RT_ERR_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d, -2 = from the camera rays
+    if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
         long v = std::atol(e);
         if (v > 0) h->max_band_pixels = (size_t)v;
     }
-    bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess &&
-              hipMalloc(&h->d_qcounts, sizeof(uint32_t) * kQCounts) == hipSuccess;
+    bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts) == hipSuccess;
+    if (ok) h->d_qcounts = (uint32_t*)(h->d_counters + CNT_N);
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     if (!ok) { rt_destroy(h); return RT_ERR_DEVICE; }
     *out = h;
@@ -317,7 +390,7 @@ void rt_destroy(rt_handle* h) {
     (void)hipSetDevice(h->device);
     free_frame_buffers(h);
     for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_counters,
-                    (void*)h->d_qcounts, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
+                    (void*)h->stack_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -444,6 +517,10 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     h->has_box = any_box ? 1 : 0;
     h->all_opaque = 1;
     for (int s = 0; s < S; ++s) if (sf[s].transp != 0.f) h->all_opaque = 0;
+    h->both_children = false;
+    for (int m = 0; m < M; ++m) if (mats[m].has_refl && mats[m].transp > 0.f) h->both_children = true;
+    h->have_history = false;
+    for (double& r : h->depth_ratio) r = 0.0;
     // algorithmic FP32 flop per shaded hit: per shadow ray the surface tests + 26 for building the
     // ray; per (hit, light) 30 for the sampling basis + 52 for the Phong terms; 12 for the blend
     h->flop_per_hit = rays_per_hit * (test_flops + 26.0) + L * 82.0 + 12.0;
@@ -507,7 +584,7 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
     if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "debug probe is limited to one band");
     if (rows.size() > h->row_y_cap) {
         if (h->d_row_y) (void)hipFree(h->d_row_y);
-        h->d_row_y = nullptr; h->row_y_cap = 0;
+        h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
         HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
         h->row_y_cap = rows.size();
     }

@@ -7,6 +7,8 @@
 #define RT_EPS 1e-6   // /root/reference/utils.py:6
 #define RT_EPSF 1e-6f
 #define RT_TRACE_BLOCK 512  // threads per workgroup of the ray-tree kernel
+#define RT_TAIL_BLOCK 512   // threads per workgroup of its run-to-completion variant
+#define RT_SURF_TILE 512    // surfaces staged in LDS at a time (512 x 64 B = 32 KiB)
 
 // ---- float64 surface record used by the ray-tree kernel -------------------------
 // One 64-byte record per surface, file order.  All lanes of a wave test the same
@@ -134,8 +136,12 @@ struct TraceArgs {
     size_t npix;           // pixels of the band
     unsigned long long* counters;
     int depth;
+    RayQueue stack;        // tail kernel only: parked children, [level][thread]; tp.w = depth of the parked ray
+    uint32_t stack_levels; // slots per thread (0: the scene has no material with both children)
 };
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
+// follows every ray of a.in (depth a.depth >= 1) to the recursion limit; n_surfaces must fit one LDS tile (RT_SURF_TILE)
+void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s);
 
 enum { SHADE_AUTO = 0, SHADE_GENERAL = 1 };
 struct ShadeArgs {
@@ -159,4 +165,4 @@ struct ShadeArgs {
 };
 void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s);
 
-void rt_launch_resolve(const double* accum, int64_t n_values, float* out_f32, uint8_t* out_u8, hipStream_t s);
+void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s);

@@ -869,23 +869,27 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
 // uint8 truncation (np.uint8, ray_tracer.py:438)
 // ---------------------------------------------------------------------------------------
 // accum is planar ([3][npix]: a wave's accumulator updates of one channel then touch neighbouring
-// addresses); the images are interleaved RGB
-__global__ __launch_bounds__(256) void k_resolve(const double* __restrict__ accum, int64_t n, float* out_f32, uint8_t* out_u8) {
+// addresses); the images are interleaved RGB.  Every accumulator read is set back to zero, so the
+// next band starts from cleared accumulators without a separate fill.
+__global__ __launch_bounds__(256) void k_resolve(double* __restrict__ accum, int64_t npix, float* out_f32, uint8_t* out_u8) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    const int64_t npix = n / 3;
-    for (; i < n; i += stride) {
-        double c = accum[(i % 3) * npix + i / 3];
-        c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
-        float v = (float)(c * 255.0);
-        if (out_f32) out_f32[i] = v;
-        if (out_u8) out_u8[i] = (uint8_t)v;  // same value np.uint8() gives for the float image
+    for (; i < npix; i += stride) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            double c = accum[ch * npix + i];
+            accum[ch * npix + i] = 0.0;
+            c = c < 0.0 ? 0.0 : (c > 1.0 ? 1.0 : c);
+            const float v = (float)(c * 255.0);
+            if (out_f32) out_f32[3 * i + ch] = v;
+            if (out_u8) out_u8[3 * i + ch] = (uint8_t)v;  // same value np.uint8() gives for the float image
+        }
     }
 }
 
-void rt_launch_resolve(const double* accum, int64_t n_values, float* out_f32, uint8_t* out_u8, hipStream_t s) {
-    int64_t blocks = (n_values + 255) / 256;
+void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s) {
+    int64_t blocks = (n_pixels + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, accum, n_values, out_f32, out_u8);
+    hipLaunchKernelGGL(k_resolve, dim3((unsigned)blocks), dim3(256), 0, s, accum, n_pixels, out_f32, out_u8);
 }

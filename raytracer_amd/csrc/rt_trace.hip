@@ -28,7 +28,7 @@
 #pragma clang fp contract(off)
 
 #define TRACE_BLOCK RT_TRACE_BLOCK
-#define SURF_TILE 512  // 512 x 64 B = 32 KiB of LDS per workgroup
+#define SURF_TILE RT_SURF_TILE
 
 struct d3 { double x, y, z; };
 __device__ __forceinline__ d3 D3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -120,6 +120,93 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned int v) {
     return s;
 }
 
+// find_nearest_intersection (scene_settings.py:31-46) over tile[0..ns): file order, strict '<'
+__device__ __forceinline__ void nearest_in_tile(const SurfD* tile, int ns, int s0, d3 o, d3 d, double& best, int& bs, int& bcode) {
+    for (int j = 0; j < ns; ++j) {
+        const SurfD& sf = tile[j];
+        double t; int code = 0; bool hit;
+        if (sf.type == RT_SURF_SPHERE) hit = sphere_t(sf, o, d, t);
+        else if (sf.type == RT_SURF_PLANE) hit = plane_t(sf, o, d, t);
+        else hit = box_t(sf, o, d, t, code);
+        if (hit && t > RT_EPS && t < best) { best = t; bs = s0 + j; bcode = code; }
+    }
+}
+
+// hit point, normal and own-surface flags of the winning surface
+struct HitFrame { d3 P, n; uint32_t flags; int mat; };
+__device__ __forceinline__ HitFrame hit_frame(const SurfD& sf, d3 o, d3 d, double best, int bcode) {
+    HitFrame f;
+    f.n = D3(0, 0, 0);
+    f.flags = 0;
+    f.mat = sf.mat;
+    f.P = add(o, scl(d, best));  // scene_settings.py:45
+    const d3 P = f.P;
+    if (sf.type == RT_SURF_SPHERE) {
+        d3 c = D3(sf.d[0], sf.d[1], sf.d[2]);
+        d3 oc = sub(P, c);
+        f.n = divs(oc, sf.d[3]);                                   // sphere.py:62-63
+        if (dots(oc, oc) - sf.d[5] > 0) f.flags |= HF_CBATCH_POS;  // sphere.py:93
+        if (dotb(oc, oc) - sf.d[4] > 0) f.flags |= HF_CDOT_POS;    // sphere.py:38
+    } else if (sf.type == RT_SURF_PLANE) {
+        f.n = D3(sf.d[0], sf.d[1], sf.d[2]);
+    } else {
+        if (bcode == 0) f.flags |= HF_NO_OWN;
+        else {
+            int ax = (bcode - 1) >> 1; bool pos = (bcode - 1) & 1;
+            double sg = pos ? 1.0 : -1.0;
+            f.n = D3(ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0);
+            double pa = ax == 0 ? P.x : (ax == 1 ? P.y : P.z);
+            double face = pos ? (ax == 0 ? sf.d[3] : (ax == 1 ? sf.d[4] : sf.d[5]))
+                              : (ax == 0 ? sf.d[0] : (ax == 1 ? sf.d[1] : sf.d[2]));
+            if (pos ? (pa > face) : (pa < face)) f.flags |= HF_BOX_OUTSIDE;
+        }
+    }
+    return f;
+}
+
+__device__ __forceinline__ void store_shade(const ShadeQueue& q, uint32_t slot, d3 o, const HitFrame& f, float tr, float tg, float tb,
+                                            float transp, uint32_t lpix, uint32_t gpix, uint32_t node, int bs) {
+    d3 view = normalize(sub(o, f.P));           // ray_tracer.py:275
+    float om = (float)(1.0 - (double)transp);   // material.py:28
+    q.r0[slot] = make_float4((float)f.P.x, (float)f.P.y, (float)f.P.z, (float)f.n.x);
+    q.r1[slot] = make_float4((float)f.n.y, (float)f.n.z, (float)view.x, (float)view.y);
+    q.r2[slot] = make_float4((float)view.z, tr * om, tg * om, tb * om);
+    q.r3[slot] = make_uint4(lpix, gpix, node, (uint32_t)bs | (f.flags << 24));
+}
+
+__device__ __forceinline__ void store_debug(const HitDebug& g, uint32_t slot, uint32_t gpix, uint32_t node, int bs, bool hit, double best,
+                                            const HitFrame& f) {
+    g.gpixel[slot] = gpix; g.node[slot] = node; g.surf[slot] = bs;
+    g.t[slot] = hit ? best : 0.0; g.flags[slot] = f.flags;
+    g.P[slot * 3 + 0] = f.P.x; g.P[slot * 3 + 1] = f.P.y; g.P[slot * 3 + 2] = f.P.z;
+    g.n[slot * 3 + 0] = f.n.x; g.n[slot * 3 + 1] = f.n.y; g.n[slot * 3 + 2] = f.n.z;
+}
+
+// throughput * background (ray_tracer.py:261-262, 269-270)
+__device__ __forceinline__ void add_background(const TraceArgs& a, uint32_t lpix, float r, float g, float b) {
+    unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(r * a.fp.bg[0]));
+    unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(g * a.fp.bg[1]));
+    unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(b * a.fp.bg[2]));
+}
+
+// Camera.get_ray (camera.py:31-44) for band pixel idx: global pixel index, origin, direction
+__device__ __forceinline__ void camera_ray(const TraceArgs& a, uint32_t idx, uint32_t& gpix, d3& o, d3& d) {
+    const int W = a.fp.width;
+    int r = (int)(idx / (uint32_t)W), px = (int)(idx % (uint32_t)W);
+    int py = a.fp.row_y[r];
+    gpix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
+    const CameraD& c = a.cam;
+    double sh = c.swidth * ((double)a.fp.height / (double)W);
+    double nx = -((px + 0.5) / W - 0.5);
+    double ny = (py + 0.5) / a.fp.height - 0.5;
+    d3 cp = D3(c.pos[0], c.pos[1], c.pos[2]);
+    d3 centre = add(cp, scl(D3(c.fwd[0], c.fwd[1], c.fwd[2]), c.sdist));
+    d3 pt = add(add(centre, scl(D3(c.right[0], c.right[1], c.right[2]), nx * c.swidth)),
+                scl(D3(c.up[0], c.up[1], c.up[2]), -ny * sh));
+    d = normalize(sub(pt, cp));
+    o = cp;
+}
+
 template <bool PRIMARY>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     __shared__ SurfD tile[SURF_TILE];
@@ -152,21 +239,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         uint32_t lpix = 0, node = 1, gpix = 0;
         if (active) {
             if (PRIMARY) {
-                // Camera.get_ray (camera.py:31-44)
                 lpix = idx;
-                int r = (int)(idx / (uint32_t)W), px = (int)(idx % (uint32_t)W);
-                int py = a.fp.row_y[r];
-                gpix = (uint32_t)py * (uint32_t)W + (uint32_t)px;
-                const CameraD& c = a.cam;
-                double sh = c.swidth * ((double)a.fp.height / (double)W);
-                double nx = -((px + 0.5) / W - 0.5);
-                double ny = (py + 0.5) / a.fp.height - 0.5;
-                d3 cp = D3(c.pos[0], c.pos[1], c.pos[2]);
-                d3 centre = add(cp, scl(D3(c.fwd[0], c.fwd[1], c.fwd[2]), c.sdist));
-                d3 pt = add(add(centre, scl(D3(c.right[0], c.right[1], c.right[2]), nx * c.swidth)),
-                            scl(D3(c.up[0], c.up[1], c.up[2]), -ny * sh));
-                d = normalize(sub(pt, cp));
-                o = cp;
+                camera_ray(a, idx, gpix, o, d);
             } else {
                 const double2 qa = a.in.oa[idx], qb = a.in.ob[idx], qc = a.in.oc[idx];
                 const uint4 qt = a.in.tp[idx];
@@ -200,66 +274,24 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                 for (int i = threadIdx.x; i < ns * 8; i += TRACE_BLOCK) dst[i] = src[i];
                 __syncthreads();
             }
-            if (active) {
-                for (int j = 0; j < ns; ++j) {
-                    const SurfD& sf = tile[j];
-                    double t; int code = 0; bool hit;
-                    if (sf.type == RT_SURF_SPHERE) hit = sphere_t(sf, o, d, t);
-                    else if (sf.type == RT_SURF_PLANE) hit = plane_t(sf, o, d, t);
-                    else hit = box_t(sf, o, d, t, code);
-                    if (hit && t > RT_EPS && t < best) { best = t; bs = s0 + j; bcode = code; }
-                }
-            }
+            if (active) nearest_in_tile(tile, ns, s0, o, d, best, bs, bcode);
         }
 
         // ---- hit point, normal, own-surface flags --------------------------------------
         const bool hit = active && bs >= 0;
-        d3 P = D3(0, 0, 0), n = D3(0, 0, 0);
-        uint32_t flags = 0;
-        int mat = 0;
-        if (hit) {
-            const SurfD sf = a.surf[bs];
-            mat = sf.mat;
-            P = add(o, scl(d, best));  // scene_settings.py:45
-            if (sf.type == RT_SURF_SPHERE) {
-                d3 c = D3(sf.d[0], sf.d[1], sf.d[2]);
-                d3 oc = sub(P, c);
-                n = divs(oc, sf.d[3]);                               // sphere.py:62-63
-                if (dots(oc, oc) - sf.d[5] > 0) flags |= HF_CBATCH_POS;  // sphere.py:93
-                if (dotb(oc, oc) - sf.d[4] > 0) flags |= HF_CDOT_POS;    // sphere.py:38
-            } else if (sf.type == RT_SURF_PLANE) {
-                n = D3(sf.d[0], sf.d[1], sf.d[2]);
-            } else {
-                if (bcode == 0) flags |= HF_NO_OWN;
-                else {
-                    int ax = (bcode - 1) >> 1; bool pos = (bcode - 1) & 1;
-                    double sg = pos ? 1.0 : -1.0;
-                    n = D3(ax == 0 ? sg : 0.0, ax == 1 ? sg : 0.0, ax == 2 ? sg : 0.0);
-                    double pa = ax == 0 ? P.x : (ax == 1 ? P.y : P.z);
-                    double face = pos ? (ax == 0 ? sf.d[3] : (ax == 1 ? sf.d[4] : sf.d[5]))
-                                      : (ax == 0 ? sf.d[0] : (ax == 1 ? sf.d[1] : sf.d[2]));
-                    if (pos ? (pa > face) : (pa < face)) flags |= HF_BOX_OUTSIDE;
-                }
-            }
-        }
-        const MatF m = a.mat[mat];
+        HitFrame f;
+        f.P = D3(0, 0, 0); f.n = D3(0, 0, 0); f.flags = 0; f.mat = 0;
+        if (hit) f = hit_frame(a.surf[bs], o, d, best, bcode);
+        const d3 P = f.P, n = f.n;
+        const MatF m = a.mat[f.mat];
 
         if (a.dbg.capacity) {
             uint32_t slot = wave_append(a.dbg.count, active);
-            if (active && slot < a.dbg.capacity) {
-                a.dbg.gpixel[slot] = gpix; a.dbg.node[slot] = node; a.dbg.surf[slot] = bs;
-                a.dbg.t[slot] = hit ? best : 0.0; a.dbg.flags[slot] = flags;
-                a.dbg.P[slot * 3 + 0] = P.x; a.dbg.P[slot * 3 + 1] = P.y; a.dbg.P[slot * 3 + 2] = P.z;
-                a.dbg.n[slot * 3 + 0] = n.x; a.dbg.n[slot * 3 + 1] = n.y; a.dbg.n[slot * 3 + 2] = n.z;
-            }
+            if (active && slot < a.dbg.capacity) store_debug(a.dbg, slot, gpix, node, bs, hit, best, f);
         }
 
         // ---- ray left the scene: throughput * background (ray_tracer.py:269-270) ----------
-        if (active && !hit) {
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(tr * a.fp.bg[0]));
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(tg * a.fp.bg[1]));
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(tb * a.fp.bg[2]));
-        }
+        if (active && !hit) add_background(a, lpix, tr, tg, tb);
 
         // ---- reserve queue slots: ONE atomic per workgroup and queue ------------------------------
         // (a single counter word sustains only ~90 atomics/us: per-wave reservations of three
@@ -289,13 +321,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         // ---- shading record -----------------------------------------------------------
         if (push_s) {
             if (slot_s < a.shade.capacity) {
-                const uint32_t slot = slot_s;
-                d3 view = normalize(sub(o, P));  // ray_tracer.py:275
-                float om = (float)(1.0 - (double)m.transp);  // material.py:28
-                a.shade.r0[slot] = make_float4((float)P.x, (float)P.y, (float)P.z, (float)n.x);
-                a.shade.r1[slot] = make_float4((float)n.y, (float)n.z, (float)view.x, (float)view.y);
-                a.shade.r2[slot] = make_float4((float)view.z, tr * om, tg * om, tb * om);
-                a.shade.r3[slot] = make_uint4(lpix, gpix, node, (uint32_t)bs | (flags << 24));
+                store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
                 n_shaded += 1;
             } else ovf_shade += 1;
         }
@@ -304,9 +330,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         {
             const float cr = tr * m.kr[0], cg = tg * m.kr[1], cb = tb * m.kr[2];
             if (want_r && child_cut) {  // depth limit: the child returns the background untraced (:261-262)
-                unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(cr * a.fp.bg[0]));
-                unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(cg * a.fp.bg[1]));
-                unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(cb * a.fp.bg[2]));
+                add_background(a, lpix, cr, cg, cb);
                 n_cut += 1;
             }
             if (push_r) {
@@ -325,9 +349,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         {
             const float cr = tr * m.transp, cg = tg * m.transp, cb = tb * m.transp;
             if (want_t && child_cut) {
-                unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], (double)(cr * a.fp.bg[0]));
-                unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], (double)(cg * a.fp.bg[1]));
-                unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], (double)(cb * a.fp.bg[2]));
+                add_background(a, lpix, cr, cg, cb);
                 n_cut += 1;
             }
             if (push_t) {
@@ -353,6 +375,150 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         if (s_or) atomicAdd(&a.counters[CNT_OVERFLOW_RAY], s_or);
         if (s_os) atomicAdd(&a.counters[CNT_OVERFLOW_SHADE], s_os);
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// Tail of the ray tree: every lane takes one ray of the input queue and follows it to the
+// recursion limit inside this launch.  Deep levels hold few rays, so one launch per level is
+// bound by the latency of a launch and of one dependent float64 chain; here the levels of one
+// lane follow each other without queue round trips.  A hit with two children continues with
+// the reflection child and parks the transparency child on the lane's stack (one slot per
+// level, laid out [level][thread] so a wave's accesses stay contiguous).  All rays of a lane's
+// subtree belong to one pixel.  The workgroup steps through the levels together so that shade
+// records are reserved with ONE atomic per workgroup and step (per-wave reservations would
+// serialise on the counter word).  Needs the whole surface list in one LDS tile.
+// ---------------------------------------------------------------------------------------
+#define TAIL_BLOCK RT_TAIL_BLOCK
+template <bool PRIMARY>
+__global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
+    __shared__ SurfD tile[SURF_TILE];
+    __shared__ uint32_t s_cnt[TAIL_BLOCK / 64];
+    __shared__ uint32_t s_base;
+    const int S = a.fp.n_surfaces, W = a.fp.width;
+    uint32_t count;
+    if (PRIMARY) count = (uint32_t)a.fp.band_rows * (uint32_t)W;
+    else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
+    {
+        const double* src = (const double*)a.surf;
+        double* dst = (double*)tile;
+        for (int i = threadIdx.x; i < S * 8; i += TAIL_BLOCK) dst[i] = src[i];
+        __syncthreads();
+    }
+    unsigned int n_primary = 0, n_traced = 0, n_cut = 0, n_shaded = 0, ovf_ray = 0, ovf_shade = 0;
+    const uint32_t n_threads = gridDim.x * TAIL_BLOCK;
+    const uint32_t tid = blockIdx.x * TAIL_BLOCK + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t base = blockIdx.x * TAIL_BLOCK; base < count; base += n_threads) {
+        const uint32_t idx = base + threadIdx.x;
+        bool have = idx < count;
+        d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
+        float tr = 1.f, tg = 1.f, tb = 1.f;
+        uint32_t lpix = 0, node = 1, gpix = 0;
+        int depth = a.depth;
+        uint32_t sp = 0;  // parked children of this lane
+        if (have && PRIMARY) {
+            lpix = idx;
+            camera_ray(a, idx, gpix, o, d);
+        } else if (have) {
+            const double2 qa = a.in.oa[idx], qb = a.in.ob[idx], qc = a.in.oc[idx];
+            const uint4 qt = a.in.tp[idx];
+            o = D3(qa.x, qa.y, qb.x);
+            d = D3(qb.y, qc.x, qc.y);
+            tr = __uint_as_float(qt.x); tg = __uint_as_float(qt.y); tb = __uint_as_float(qt.z);
+            lpix = qt.w; node = a.in.node[idx];
+            int r = (int)(lpix / (uint32_t)W), px = (int)(lpix % (uint32_t)W);
+            gpix = (uint32_t)a.fp.row_y[r] * (uint32_t)W + (uint32_t)px;
+        }
+        while (__syncthreads_or(have)) {
+            double best = INFINITY;
+            int bs = -1, bcode = 0;
+            if (have) {
+                if (PRIMARY && depth == 0) n_primary += 1; else n_traced += 1;
+                nearest_in_tile(tile, S, 0, o, d, best, bs, bcode);
+            }
+            const bool hit = have && bs >= 0;
+            HitFrame f;
+            f.P = D3(0, 0, 0); f.n = D3(0, 0, 0); f.flags = 0; f.mat = 0;
+            if (hit) f = hit_frame(tile[bs], o, d, best, bcode);
+            const MatF m = a.mat[f.mat];
+            if (a.dbg.capacity) {
+                uint32_t slot = wave_append(a.dbg.count, have);
+                if (have && slot < a.dbg.capacity) store_debug(a.dbg, slot, gpix, node, bs, hit, best, f);
+            }
+            if (have && !hit) add_background(a, lpix, tr, tg, tb);
+            const unsigned long long bs_ = __ballot(hit);
+            if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bs_);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+#pragma unroll
+                for (int w = 0; w < TAIL_BLOCK / 64; ++w) { const uint32_t c = s_cnt[w]; s_cnt[w] = total; total += c; }
+                s_base = total ? atomicAdd(a.shade.count, total) : 0u;
+            }
+            __syncthreads();
+            const uint32_t slot_s = s_base + s_cnt[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
+            if (hit) {
+                if (slot_s < a.shade.capacity) {
+                    store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
+                    n_shaded += 1;
+                } else ovf_shade += 1;
+            }
+            const bool cut = (depth + 1) >= a.fp.max_rec;
+            const bool want_r = hit && m.has_refl, want_t = hit && m.transp > 0.f;
+            if (want_r && cut) { add_background(a, lpix, tr * m.kr[0], tg * m.kr[1], tb * m.kr[2]); n_cut += 1; }
+            if (want_t && cut) { add_background(a, lpix, tr * m.transp, tg * m.transp, tb * m.transp); n_cut += 1; }
+            const bool go_r = want_r && !cut, go_t = want_t && !cut;
+            if (go_r && go_t) {
+                // park the transparency child (ray_tracer.py:226-239)
+                if (sp < a.stack_levels) {
+                    const size_t slot = (size_t)sp * n_threads + tid;
+                    d3 to = add(f.P, scl(d, RT_EPS));
+                    a.stack.oa[slot] = make_double2(to.x, to.y); a.stack.ob[slot] = make_double2(to.z, d.x);
+                    a.stack.oc[slot] = make_double2(d.y, d.z);
+                    a.stack.tp[slot] = make_uint4(__float_as_uint(tr * m.transp), __float_as_uint(tg * m.transp),
+                                                  __float_as_uint(tb * m.transp), (uint32_t)(depth + 1));
+                    a.stack.node[slot] = node * 2u + 1u;
+                    sp += 1;
+                } else ovf_ray += 1;
+            }
+            if (go_r) {  // reflection child (ray_tracer.py:192-207)
+                d3 rd = sub(d, scl(f.n, 2 * dotb(d, f.n)));  // ray_tracer.py:126
+                o = add(f.P, scl(f.n, RT_EPS));              // ray_tracer.py:198
+                d = rd;
+                tr *= m.kr[0]; tg *= m.kr[1]; tb *= m.kr[2];
+                node = node * 2u; depth += 1;
+            } else if (go_t) {  // transparency child, same direction (ray_tracer.py:230)
+                o = add(f.P, scl(d, RT_EPS));
+                tr *= m.transp; tg *= m.transp; tb *= m.transp;
+                node = node * 2u + 1u; depth += 1;
+            } else if (have && sp > 0) {
+                sp -= 1;
+                const size_t slot = (size_t)sp * n_threads + tid;
+                const double2 qa = a.stack.oa[slot], qb = a.stack.ob[slot], qc = a.stack.oc[slot];
+                const uint4 qt = a.stack.tp[slot];
+                o = D3(qa.x, qa.y, qb.x);
+                d = D3(qb.y, qc.x, qc.y);
+                tr = __uint_as_float(qt.x); tg = __uint_as_float(qt.y); tb = __uint_as_float(qt.z);
+                depth = (int)qt.w; node = a.stack.node[slot];
+            } else have = false;
+        }
+    }
+    unsigned long long s_tr = wave_sum(n_traced), s_cut = wave_sum(n_cut), s_sh = wave_sum(n_shaded);
+    unsigned long long s_or = wave_sum(ovf_ray), s_os = wave_sum(ovf_shade);
+    unsigned long long s_pr = wave_sum(n_primary);
+    if (lane == 0) {
+        if (s_pr) atomicAdd(&a.counters[CNT_PRIMARY], s_pr);
+        if (s_tr) atomicAdd(&a.counters[CNT_SECONDARY], s_tr);
+        if (s_cut) atomicAdd(&a.counters[CNT_DEPTH_CUT], s_cut);
+        if (s_sh) atomicAdd(&a.counters[CNT_SHADED], s_sh);
+        if (s_or) atomicAdd(&a.counters[CNT_OVERFLOW_RAY], s_or);
+        if (s_os) atomicAdd(&a.counters[CNT_OVERFLOW_SHADE], s_os);
+    }
+}
+
+void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s) {
+    if (a.depth == 0) hipLaunchKernelGGL(k_trace_tail<true>, dim3(blocks), dim3(TAIL_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(k_trace_tail<false>, dim3(blocks), dim3(TAIL_BLOCK), 0, s, a);
 }
 
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s) {

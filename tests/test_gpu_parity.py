@@ -242,6 +242,7 @@ def test_row_bands_and_queue_growth(oracle, tmp_path, monkeypatch):
     """Frames larger than a band are rendered in row bands; a ray tree that outgrows the queues makes the
     library retry with fewer rows and, at one row, with larger queues -- the image does not change."""
     monkeypatch.setenv("RT_MAX_BAND_PIXELS", "2048")   # read by rt_create: bands of 2048 pixels
+    monkeypatch.setenv("RT_TAIL_FROM", "0")            # one launch per level, so every level goes through the ray queues
     r = runtime.Renderer(0)
     try:
         sc = scene("transparency_v7")
@@ -264,5 +265,42 @@ def test_row_bands_and_queue_growth(oracle, tmp_path, monkeypatch):
         assert cnt["secondary"] > 200 * w * h        # really a deep tree
         assert counters_of(st) == cnt
         assert_parity(u8, ref, bar=0.995)            # 2048 pixels
+    finally:
+        r.close()
+
+
+BINARY_TREE = ("cam 0 0 6  0 0 0  0 1 0  1 1\nset 0.1 0.1 0.1 2 9\nmtl 0.5 0.5 0.5  1 1 1  0.5 0.5 0.5  10 0.5\n"
+               "mtl 0.7 0.2 0.2  1 1 1  0 0 0  10 0\nmtl 0.2 0.7 0.2  1 1 1  0.4 0.4 0.4  10 0\n"
+               "sph 0 0 0 1 1\nsph 0 0 -3 1.5 1\nsph 2.2 0 0 1 3\nsph -2.2 0 0 1 1\npln 0 1 0 -1.2 2\npln 0 0 1 -6 1\nbox 0 1.8 0 0.8 1\n"
+               "lgt 3 4 5  1 1 1  1 0.5 1\n")
+
+
+@pytest.mark.parametrize("tail_from", ["0", "1", "3", "-2", "auto"])
+def test_run_to_completion_kernel_matches_level_launches(oracle, tmp_path, monkeypatch, tail_from):
+    """The deep levels of the ray tree run either as one launch per level or inside one launch that follows every
+    ray to the recursion limit (RT_TAIL_FROM picks the depth of the switch; -2 = from the camera rays on).  Same
+    queries bit for bit, same counters, same image -- on a chain scene and on a binary tree that parks children."""
+    if tail_from == "auto":
+        monkeypatch.delenv("RT_TAIL_FROM", raising=False)
+    else:
+        monkeypatch.setenv("RT_TAIL_FROM", tail_from)
+    r = runtime.Renderer(0)
+    try:
+        for sc, w, h in ((scene("pool"), 96, 54), (R.parse_scene_file(write_scene(tmp_path, BINARY_TREE)), 64, 36)):
+            r.set_scene(sc)
+            for _ in range(2):   # the second frame has the first one's per-depth ray counts to choose from
+                _, u8, st = r.render_rows(w, h, seed=3)
+            ref, cnt = oracle.render_frame(sc, w, h, seed=3, threads=THREADS)
+            assert counters_of(st) == cnt
+            assert_parity(u8, ref, bar=0.999 if w * h > 4000 else 0.995)
+            xs, ys = grid(w, h)
+            _, _, oh = oracle.render_pixels(sc, w, h, xs, ys, seed=3, record_hits=True)
+            hb = r.debug_hits(w, h, capacity=len(oh) + 64)
+            assert hb["count"] == len(oh)
+            want = {(o[0], o[1]): o for o in oh}
+            for i in range(hb["count"]):
+                o = want[(int(hb["pixel"][i]), int(hb["node"][i]))]
+                assert (o[2], o[3]) == (hb["surf"][i], hb["t"][i])
+                assert o[4] == tuple(hb["P"][i]) and o[5] == tuple(hb["n"][i])
     finally:
         r.close()

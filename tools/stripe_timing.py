@@ -10,11 +10,12 @@ from raytracer_amd.distributed import stripe_rows_for, max_rows_per_rank
 W, H = 3840, 2160
 r = runtime.Renderer(0)
 r.set_scene(R.parse_scene_file("scenes/pool_n16.txt"))
-for world in (1, 2, 4, 8):
+worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+for world in worlds:
     sr = stripe_rows_for(H, world)
     tile = torch.zeros((max_rows_per_rank(H, world, sr), W, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-    for rank in (0, world - 1):
+    for rank in sorted({0, world - 1}):
         ts = []
         for it in range(6):
             torch.cuda.synchronize(); t0 = time.perf_counter()
