@@ -260,7 +260,10 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
             break;
         }
         int blocks = max_blocks;
-        if (d == 0) blocks = (int)std::min<size_t>((pixels + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
+        if (d == 0) {  // camera rays come in 8 x 8 pixel tiles
+            const size_t slots = ((size_t)(p->width + 7) / 8) * ((size_t)(n_rows + 7) / 8) * 64;
+            blocks = (int)std::min<size_t>((slots + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
+        }
         rt_launch_trace(ta, std::max(blocks, 1), st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[1], st));

@@ -207,6 +207,22 @@ __device__ __forceinline__ void camera_ray(const TraceArgs& a, uint32_t idx, uin
     o = cp;
 }
 
+// Camera rays are enumerated in 8 x 8 pixel tiles, one tile per wave: the 64 hits of a wave (and of
+// the 64-hit chunks the shading kernel works on) then lie close together on the surfaces, so their
+// per-light classification and undecided sample tiles agree far more often than for a 64 x 1 strip.
+// Slots of tiles that overhang the band's right or bottom edge stay idle.
+__device__ __forceinline__ uint32_t primary_slots(const TraceArgs& a) {
+    return (((uint32_t)a.fp.width + 7u) >> 3) * (((uint32_t)a.fp.band_rows + 7u) >> 3) * 64u;
+}
+__device__ __forceinline__ bool primary_pixel(const TraceArgs& a, uint32_t idx, uint32_t& lpix) {
+    const uint32_t tiles_x = ((uint32_t)a.fp.width + 7u) >> 3;
+    const uint32_t t = idx >> 6, within = idx & 63u;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    const uint32_t r = ty * 8u + (within >> 3), px = tx * 8u + (within & 7u);
+    lpix = r * (uint32_t)a.fp.width + px;
+    return r < (uint32_t)a.fp.band_rows && px < (uint32_t)a.fp.width;
+}
+
 template <bool PRIMARY>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     __shared__ SurfD tile[SURF_TILE];
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     const int S = a.fp.n_surfaces;
     const int W = a.fp.width;
     uint32_t count;
-    if (PRIMARY) count = (uint32_t)a.fp.band_rows * (uint32_t)W;
+    if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
 
     const bool single_tile = S <= SURF_TILE;
@@ -233,14 +249,14 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     const uint32_t rounded = (count + TRACE_BLOCK - 1) / TRACE_BLOCK * TRACE_BLOCK;
     for (uint32_t base = blockIdx.x * TRACE_BLOCK; base < rounded; base += stride) {
         const uint32_t idx = base + threadIdx.x;
-        const bool active = idx < count;
+        bool active = idx < count;
         d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
         float tr = 1.f, tg = 1.f, tb = 1.f;
         uint32_t lpix = 0, node = 1, gpix = 0;
+        if (PRIMARY) active = active && primary_pixel(a, idx, lpix);
         if (active) {
             if (PRIMARY) {
-                lpix = idx;
-                camera_ray(a, idx, gpix, o, d);
+                camera_ray(a, lpix, gpix, o, d);
             } else {
                 const double2 qa = a.in.oa[idx], qb = a.in.ob[idx], qc = a.in.oc[idx];
                 const uint4 qt = a.in.tp[idx];
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     __shared__ uint32_t s_base;
     const int S = a.fp.n_surfaces, W = a.fp.width;
     uint32_t count;
-    if (PRIMARY) count = (uint32_t)a.fp.band_rows * (uint32_t)W;
+    if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
     {
         const double* src = (const double*)a.surf;
@@ -416,9 +432,9 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
         uint32_t lpix = 0, node = 1, gpix = 0;
         int depth = a.depth;
         uint32_t sp = 0;  // parked children of this lane
+        if (PRIMARY) have = have && primary_pixel(a, idx, lpix);
         if (have && PRIMARY) {
-            lpix = idx;
-            camera_ray(a, idx, gpix, o, d);
+            camera_ray(a, lpix, gpix, o, d);
         } else if (have) {
             const double2 qa = a.in.oa[idx], qb = a.in.ob[idx], qc = a.in.oc[idx];
             const uint4 qt = a.in.tp[idx];

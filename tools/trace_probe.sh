@@ -1,4 +1,5 @@
 #!/bin/bash
-# development probe (GPU box): kernel trace of two headline frames; per-depth k_trace durations are read from the csv
+# development probe (GPU box): kernel trace of one rank's share of the headline frame at world size $1 (default 8)
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/prof_trace.log 2>&1
+rm -rf gpurun_out/prof_trace
+timeout -s KILL 120 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_trace -- python3 tools/stripe_timing.py ${1:-8} > gpurun_out/prof_trace.log 2>&1
