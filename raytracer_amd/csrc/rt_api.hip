@@ -40,11 +40,6 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
-// A level with fewer rays than this per CU goes to the run-to-completion kernel.  Measured on the 4K pool frame
-// (2.2 M rays at depth 1, 1.0 M at depth 2): starting the tail at depth 2 is fastest there, at depth 1 for an
-// eighth of the frame; an earlier start saves queue traffic and launches but orders the shade queue less
-// coherently, which costs more in the shading kernel than it saves here.
-constexpr double kTailRaysPerCu = 6144.0;
 constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 
@@ -84,9 +79,7 @@ struct rt_handle {
     RayQueue stack{};                // parked children, [level][thread]
     void* stack_mem = nullptr;
     size_t stack_slots = 0;
-    int tail_override = -1;          // RT_TAIL_FROM: -1 automatic, 0 never, d >= 1 always from depth d, -2 camera rays too
-    bool have_history = false;       // depth_ratio holds the previous band's rays per pixel at each depth
-    double depth_ratio[32] = {};
+    int tail_override = -1;          // RT_TAIL_FROM: -1 automatic, 0 never, d >= 1 from depth d on
     size_t accum_zero_prefix = 0;    // accumulator values [0, prefix) are known to be zero (k_resolve clears what it reads)
     std::vector<int32_t> rows_on_device;  // what d_row_y holds
     uint2* d_deferred = nullptr;
@@ -123,6 +116,9 @@ void free_frame_buffers(rt_handle* h) {
 }
 
 // carve the SoA queues out of one arena
+// camera rays are enumerated in 8 x 8 pixel tiles; each owns one shade slot (rt_trace.hip: primary_slots)
+size_t primary_slots(size_t width, size_t rows) { return ((width + 7) / 8) * ((rows + 7) / 8) * 64; }
+
 int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const int lights = h->L > 0 ? h->L : 1;
     if (pixels <= h->band_capacity && lights <= h->arena_lights) return RT_OK;
@@ -179,22 +175,18 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
         if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) rows.push_back(y);
 }
 
-// c and q mirror the device block: statistics words, then the queue counter words
-struct BandResult { unsigned long long c[CNT_N]; uint32_t q[kQCounts]; float ms_trace, ms_shade, ms_resolve; int tail_from; };
+struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
 
 // Depth from which one k_trace_tail launch replaces the per-level launches (>= depths: never).
-// Automatic mode uses the rays per pixel the previous band of this scene had at each depth (depth 2
-// before any band has run).  The choice never changes the image.
-int choose_tail_depth(const rt_handle* h, int depths, size_t pixels) {
+// Whenever the surface list fits one LDS tile the whole tree, camera rays included, runs in one
+// launch: no ray queue traffic, no launch per level (measured 0.45 ms against 0.92 ms on the 4K
+// pool frame, 0.55 against 0.89 ms on the 1080p transparency scene).  The choice never changes
+// the image.
+int choose_tail_depth(const rt_handle* h, int depths) {
     if (h->S > RT_SURF_TILE || depths < 2) return depths;
-    if (h->tail_override == -2) return 0;  // the camera rays as well: one launch for the whole tree
     if (h->tail_override == 0) return depths;
     if (h->tail_override > 0) return std::min(h->tail_override, depths);
-    if (!h->have_history) return std::min(2, depths);
-    const double limit = (double)h->n_cu * kTailRaysPerCu;
-    for (int d = 1; d < depths; ++d)
-        if (h->depth_ratio[d] * (double)pixels <= limit) return d;
-    return depths;
+    return 0;
 }
 
 int ensure_tail_stack(rt_handle* h, int blocks) {
@@ -219,6 +211,13 @@ int ensure_tail_stack(rt_handle* h, int blocks) {
 int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n_rows, float* d_f32, uint8_t* d_u8,
              hipStream_t st, bool debug, BandResult* res) {
     const size_t pixels = (size_t)n_rows * p->width;
+    const size_t slots0 = primary_slots((size_t)p->width, (size_t)n_rows);
+    // thin bands pad their tiles up to 8 rows: make room for the camera rays' slots plus as many appended hits
+    if (slots0 * 2 > (size_t)h->sq.capacity) {
+        int rc = ensure_band_capacity(h, (slots0 * 2 + kShadeFactor - 1) / kShadeFactor);
+        if (rc != RT_OK) return rc;
+    }
+    h->sq.base = (uint32_t)slots0;
     if (h->rows_on_device.size() != (size_t)n_rows || std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) {
         h->rows_on_device.clear();  // stays empty if the copy fails
         HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
@@ -241,10 +240,9 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventRecord(h->ev[0], st));
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
-    const int tail_from = choose_tail_depth(h, depths, pixels);
+    const int tail_from = choose_tail_depth(h, depths);
     const int tail_blocks = h->n_cu * 2;
     if (tail_from < depths) { int rc = ensure_tail_stack(h, tail_blocks); if (rc != RT_OK) return rc; }
-    res->tail_from = tail_from;
     for (int d = 0; d < depths && d <= tail_from; ++d) {
         TraceArgs ta{};
         ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat;
@@ -260,10 +258,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
             break;
         }
         int blocks = max_blocks;
-        if (d == 0) {  // camera rays come in 8 x 8 pixel tiles
-            const size_t slots = ((size_t)(p->width + 7) / 8) * ((size_t)(n_rows + 7) / 8) * 64;
-            blocks = (int)std::min<size_t>((slots + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
-        }
+        if (d == 0) blocks = (int)std::min<size_t>((slots0 + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
     }
     HIP_TRY(h, hipEventRecord(h->ev[1], st));
@@ -286,8 +281,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels, d_f32, d_u8, st);
     HIP_TRY(h, hipEventRecord(h->ev[3], st));
     HIP_TRY(h, hipGetLastError());
-    static_assert(offsetof(BandResult, q) == sizeof(unsigned long long) * CNT_N, "BandResult mirrors the device counter block");
-    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c) + sizeof(res->q), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipStreamSynchronize(st));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, h->ev[0], h->ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, h->ev[1], h->ev[2]));
@@ -338,9 +332,6 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
         }
-        // rays per pixel at every depth that still had a launch of its own (deeper ones keep their last value)
-        for (int d = 1; d < 32 && d < h->R && d <= br.tail_from; ++d) h->depth_ratio[d] = (double)br.q[8 + d] / (double)(n * W);
-        h->have_history = true;
         s.primary_rays += br.c[CNT_PRIMARY]; s.secondary_rays += br.c[CNT_SECONDARY];
         s.depth_cut += br.c[CNT_DEPTH_CUT]; s.shaded_points += br.c[CNT_SHADED];
         s.ms_trace += br.ms_trace; s.ms_shade += br.ms_shade; s.ms_resolve += br.ms_resolve;
@@ -374,7 +365,7 @@ int rt_create(int device, rt_handle** out) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&h->stream) != hipSuccess) { delete h; return RT_ERR_DEVICE; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
-    // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d, -2 = from the camera rays
+    // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d on (default: from the camera rays)
     if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
         long v = std::atol(e);
@@ -522,8 +513,6 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     for (int s = 0; s < S; ++s) if (sf[s].transp != 0.f) h->all_opaque = 0;
     h->both_children = false;
     for (int m = 0; m < M; ++m) if (mats[m].has_refl && mats[m].transp > 0.f) h->both_children = true;
-    h->have_history = false;
-    for (double& r : h->depth_ratio) r = 0.0;
     // algorithmic FP32 flop per shaded hit: per shadow ray the surface tests + 26 for building the
     // ray; per (hit, light) 30 for the sampling basis + 52 for the Phong terms; 12 for the blend
     h->flop_per_hit = rays_per_hit * (test_flops + 26.0) + L * 82.0 + 12.0;

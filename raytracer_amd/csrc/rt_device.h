@@ -70,6 +70,11 @@ struct RayQueue {
 #define HF_BOX_OUTSIDE 4u  // box: hit point lies strictly outside its face plane -> single-ray path not blocked
 #define HF_NO_OWN 8u       // degenerate hit (zero normal): no own-surface rule
 
+// Slots [0, base) belong to the camera rays: the ray of enumeration index i (8 x 8 pixel tiles, see
+// rt_trace.hip) owns slot i, so a 64-slot chunk is one pixel tile; a slot whose ray left the scene or
+// lies outside the band holds RT_NULL_HIT in r3.w.  Hits of deeper rays are appended from `base` on;
+// *count counts only those.
+#define RT_NULL_HIT 0xFFFFFFFFu
 struct ShadeQueue {
     float4 *r0;   // hit point xyz, normal x
     float4 *r1;   // normal yz (stored outward normal), view xy (direction towards the ray origin)
@@ -77,6 +82,7 @@ struct ShadeQueue {
     uint4 *r3;    // LOCAL pixel index inside the band, GLOBAL pixel index y*W+x (jitter key), node, surface | flags << 24
     uint32_t* count;
     uint32_t capacity;
+    uint32_t base;
 };
 
 // optional float64 record of every nearest-hit query (debug / parity tests)

@@ -150,6 +150,7 @@ struct HitRec {
     f3 P, nrm, view, wgt;
     uint32_t lpix, gpix, node, flags;
     int own_id;
+    bool valid;  // false: the slot holds no hit (RT_NULL_HIT)
 };
 
 __device__ __forceinline__ HitRec load_hit(const ShadeQueue& q, uint32_t li) {
@@ -161,14 +162,38 @@ __device__ __forceinline__ HitRec load_hit(const ShadeQueue& q, uint32_t li) {
     h.view = F3(a1.z, a1.w, a2.x);
     h.wgt = F3(a2.y, a2.z, a2.w);
     h.lpix = a3.x; h.gpix = a3.y; h.node = a3.z;
+    h.valid = a3.w != RT_NULL_HIT;
     h.flags = a3.w >> 24;
     h.own_id = (int)(a3.w & 0xFFFFFFu);
     return h;
 }
 
+// slots in use: the camera rays' own slots, then the appended hits
+__device__ __forceinline__ uint32_t queue_slots(const ShadeQueue& q) {
+    const uint32_t appended = *q.count;
+    const uint32_t room = q.capacity - q.base;
+    return q.base + (appended < room ? appended : room);
+}
+
+// The 64 records of the chunk starting at `base`, one per lane.  `active` marks lanes that hold a hit;
+// the others get a copy of the chunk's first hit so that wave-wide decisions see nothing foreign (their
+// results are dropped).  Returns false when the chunk holds no hit at all.
+__device__ __forceinline__ bool load_chunk(const ShadeQueue& q, uint32_t base, uint32_t count, uint32_t lane, HitRec& h, bool& active) {
+    const uint32_t idx = base + lane;
+    const bool in = idx < count;
+    h = load_hit(q, in ? idx : base);
+    active = in && h.valid;
+    const unsigned long long m = __ballot(active);
+    if (!m) return false;
+    if (~m) {  // a partly filled chunk (wave-uniform branch)
+        const HitRec first = load_hit(q, base + (uint32_t)__builtin_ctzll(m));
+        if (!active) h = first;
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
-    uint32_t count = *a.q.count;
-    if (count > a.q.capacity) count = a.q.capacity;
+    const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
     const float inv_n2 = 1.0f / (float)(N * N);
@@ -177,10 +202,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
 
     for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
-        const uint32_t idx = base + lane;
-        const bool active = idx < count;
-        const uint32_t li = active ? idx : base;  // idle lanes shadow item 0 of the chunk, results dropped
-        const HitRec hr = load_hit(a.q, li);
+        HitRec hr;
+        bool active;
+        if (!load_chunk(a.q, base, count, lane, hr, active)) continue;
         const f3 P = hr.P, nrm = hr.nrm, view = hr.view;
         const uint32_t gpix = hr.gpix, node = hr.node, flags = hr.flags;
         const uint32_t meta = (uint32_t)hr.own_id;
@@ -426,8 +450,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
 
 template <bool ALL_OPAQUE>
 __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
-    uint32_t count = *a.q.count;
-    if (count > a.q.capacity) count = a.q.capacity;
+    const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
     const float inv_n2 = 1.0f / (float)(N * N);
@@ -466,9 +489,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
         if (item >= n_items) { grab = grab_end; continue; }
         const uint32_t base = (item / G) << 6;
         const int l_first = (int)(item % G);
-        const uint32_t idx = base + lane;
-        const bool active = idx < count;
-        const HitRec h = load_hit(a.q, active ? idx : base);  // idle lanes shadow the chunk's first hit, results dropped
+        HitRec h;
+        bool active;
+        if (!load_chunk(a.q, base, count, lane, h, active)) continue;
         const f3 P = h.P;
         const SurfF own_sf = a.surf[h.own_id];
         const MatF m = a.mat[own_sf.mat];
@@ -648,8 +671,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
 
 template <bool HAS_BOX, bool ALL_OPAQUE>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
-    uint32_t count = *a.q.count;
-    if (count > a.q.capacity) count = a.q.capacity;
+    const uint32_t count = queue_slots(a.q);
     const uint32_t n_items = *a.deferred_count;
     const int S = a.fp.n_surfaces, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
@@ -684,9 +706,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         const uint32_t base = __builtin_amdgcn_readfirstlane(it.x);
         const int l = (int)(__builtin_amdgcn_readfirstlane(it.y) & 0xFFFFFFu);
         const uint32_t smask = __builtin_amdgcn_readfirstlane(it.y) >> 24;  // surfaces in reach of some lane
-        const uint32_t idx = base + lane;
-        const bool active = idx < count;
-        const HitRec h = load_hit(a.q, active ? idx : base);
+        HitRec h;
+        bool active;
+        if (!load_chunk(a.q, base, count, lane, h, active)) continue;  // (same chunk in all four waves)
         const f3 P = h.P;
         const uint32_t flags = h.flags;
         const int own_id = (flags & HF_NO_OWN) ? -1 : h.own_id;

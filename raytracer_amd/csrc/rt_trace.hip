@@ -275,6 +275,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
                 n_traced -= 1; n_cut += 1;
                 a.accum[(size_t)0 * a.npix + lpix] = a.fp.bg[0]; a.accum[(size_t)1 * a.npix + lpix] = a.fp.bg[1]; a.accum[(size_t)2 * a.npix + lpix] = a.fp.bg[2];
             }
+            if (idx < count) a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
             continue;
         }
 
@@ -314,7 +315,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         //  queues would serialise the whole kernel on those three words)
         const bool want_r = hit && m.has_refl;
         const bool want_t = hit && m.transp > 0.f;
-        const bool push_s = hit, push_r = want_r && !child_cut, push_t = want_t && !child_cut;
+        // camera rays own the shade slot of their enumeration index: nothing to reserve
+        const bool push_s = hit && !PRIMARY, push_r = want_r && !child_cut, push_t = want_t && !child_cut;
         const unsigned long long bs_ = __ballot(push_s), br_ = __ballot(push_r), bt_ = __ballot(push_t);
         const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         if (lane == 0) { s_cnt[0][wv] = (uint32_t)__popcll(bs_); s_cnt[1][wv] = (uint32_t)__popcll(br_); s_cnt[2][wv] = (uint32_t)__popcll(bt_); }
@@ -329,13 +331,18 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
             s_base[q] = total ? atomicAdd(counter, total) : 0u;
         }
         __syncthreads();
-        const uint32_t slot_s = s_base[0] + s_cnt[0][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
+        const uint32_t slot_s = a.shade.base + s_base[0] + s_cnt[0][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
         const uint32_t slot_r = s_base[1] + s_cnt[1][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(br_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)br_, 0u));
         const uint32_t slot_t = s_base[2] + s_cnt[2][wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bt_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bt_, 0u));
         __syncthreads();  // s_cnt / s_base are rewritten by the next iteration
 
         // ---- shading record -----------------------------------------------------------
-        if (push_s) {
+        if (PRIMARY) {
+            if (idx < count) {  // every slot of the camera rays is written: a record or the null mark
+                if (hit) { store_shade(a.shade, idx, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
+                else a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
+            }
+        } else if (push_s) {
             if (slot_s < a.shade.capacity) {
                 store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
                 n_shaded += 1;
@@ -445,6 +452,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             int r = (int)(lpix / (uint32_t)W), px = (int)(lpix % (uint32_t)W);
             gpix = (uint32_t)a.fp.row_y[r] * (uint32_t)W + (uint32_t)px;
         }
+        bool first = PRIMARY;  // first step of camera rays: their shade slot is their enumeration index
+        if (PRIMARY && !have && idx < count) a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);  // slot outside the band
         while (__syncthreads_or(have)) {
             double best = INFINITY;
             int bs = -1, bcode = 0;
@@ -462,7 +471,13 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
                 if (have && slot < a.dbg.capacity) store_debug(a.dbg, slot, gpix, node, bs, hit, best, f);
             }
             if (have && !hit) add_background(a, lpix, tr, tg, tb);
-            const unsigned long long bs_ = __ballot(hit);
+            const bool push_s = hit && !first;
+            if (first && have) {
+                if (hit) { store_shade(a.shade, idx, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
+                else a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
+            }
+            first = false;
+            const unsigned long long bs_ = __ballot(push_s);
             if (lane == 0) s_cnt[wv] = (uint32_t)__popcll(bs_);
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -472,8 +487,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
                 s_base = total ? atomicAdd(a.shade.count, total) : 0u;
             }
             __syncthreads();
-            const uint32_t slot_s = s_base + s_cnt[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
-            if (hit) {
+            const uint32_t slot_s = a.shade.base + s_base + s_cnt[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
+            if (push_s) {
                 if (slot_s < a.shade.capacity) {
                     store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
                     n_shaded += 1;

@@ -13,7 +13,8 @@ import numpy as np
 
 from . import packing
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_amd.so")
+# RT_AMD_LIB names another build of the same library (A/B measurements of two builds in one session)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_amd.so")
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_render", "rt_render_device",
            "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")

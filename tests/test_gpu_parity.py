@@ -275,10 +275,10 @@ BINARY_TREE = ("cam 0 0 6  0 0 0  0 1 0  1 1\nset 0.1 0.1 0.1 2 9\nmtl 0.5 0.5 0
                "lgt 3 4 5  1 1 1  1 0.5 1\n")
 
 
-@pytest.mark.parametrize("tail_from", ["0", "1", "3", "-2", "auto"])
+@pytest.mark.parametrize("tail_from", ["0", "1", "3", "auto"])
 def test_run_to_completion_kernel_matches_level_launches(oracle, tmp_path, monkeypatch, tail_from):
     """The deep levels of the ray tree run either as one launch per level or inside one launch that follows every
-    ray to the recursion limit (RT_TAIL_FROM picks the depth of the switch; -2 = from the camera rays on).  Same
+    ray to the recursion limit (RT_TAIL_FROM picks the depth of the switch; default: the camera rays already).  Same
     queries bit for bit, same counters, same image -- on a chain scene and on a binary tree that parks children."""
     if tail_from == "auto":
         monkeypatch.delenv("RT_TAIL_FROM", raising=False)
@@ -288,8 +288,7 @@ def test_run_to_completion_kernel_matches_level_launches(oracle, tmp_path, monke
     try:
         for sc, w, h in ((scene("pool"), 96, 54), (R.parse_scene_file(write_scene(tmp_path, BINARY_TREE)), 64, 36)):
             r.set_scene(sc)
-            for _ in range(2):   # the second frame has the first one's per-depth ray counts to choose from
-                _, u8, st = r.render_rows(w, h, seed=3)
+            _, u8, st = r.render_rows(w, h, seed=3)
             ref, cnt = oracle.render_frame(sc, w, h, seed=3, threads=THREADS)
             assert counters_of(st) == cnt
             assert_parity(u8, ref, bar=0.999 if w * h > 4000 else 0.995)
