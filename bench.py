@@ -123,6 +123,19 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    # the same frame with RT_FLAG_NO_CULL (every shadow ray against every surface): what the straightforward
+    # kernel reaches of the vector peak; outside the timed region, rank 0 of a single-GPU run only
+    brute = None
+    if world == 1 and not args.no_cull and args.workload == "pool_n16_4k":
+        drb = DistributedRenderer(renderer, W, H, flags=2)
+        drb.render(seed=0)
+        bms = bfl = 0.0
+        for i in range(2):
+            _, stb = drb.render(seed=2000 + i)
+            bms += stb["ms_shade"]; bfl += stb["flop_shade"]
+        brute = {"shade_ms_per_frame": bms / 2, "achieved": (bfl / 1e12) / (bms / 1e3), "unit": "TFLOP/s",
+                 "frac": (bfl / 1e12) / (bms / 1e3) / FP32_VECTOR_PEAK_TFLOPS}
+
     if world > 1:
         t = torch.tensor([dt, float(rays), ms_shade, flop_shade], dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -166,9 +179,12 @@ def main():
                                    "vector ALU; no dense contraction, so neither HBM nor MFMA binds it",
                          "note": "achieved = algorithmic flop (per-ray test costs fixed by convention) / measured kernel "
                                  "time; it can exceed the peak because the kernel reaches the same result without "
-                                 "performing that arithmetic (per-light surface classification, 3-FMA linear tests). "
+                                 "performing that arithmetic (per-light surface classification, 3-FMA linear tests, skipped sample "
+                                 "tiles); brute_force = the same frame and flop count with every ray tested against every "
+                                 "surface (RT_FLAG_NO_CULL). "
                                  "valu_issue = measured VALU instructions per SIMD cycle of k_shade_fast (rocprofv3 PMC, "
                                  "profiles/) against the v_fma_f32 issue ceiling measured on this chip.",
+                         "brute_force": brute,
                          "valu_issue": {"cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
                                         "ceiling_cycles_v_fma_f32": 4.0,
                                         "effective_clock_ghz": pmc.get("effective_clock_ghz")} if pmc else None},
