@@ -33,6 +33,15 @@ def max_rows_per_rank(height, world, stripe_rows):
     return max(len(rank_rows(height, world, r, stripe_rows)) for r in range(world))
 
 
+def source_rows(height, world, stripe_rows, max_rows):
+    """For every image row: its index in the rank-major stack of tiles, ``rank * max_rows + position in the rank's tile``."""
+    src = np.empty(height, dtype=np.int64)
+    for r in range(world):
+        ys = rank_rows(height, world, r, stripe_rows)
+        src[ys] = r * max_rows + np.arange(len(ys))
+    return src
+
+
 def assemble(tiles, height, width, world, stripe_rows, xp=np):
     """Rank 0: place each rank's packed rows at their image rows.  ``tiles[r]`` is (>=rows_r, W, 3)."""
     if xp is np:
@@ -50,45 +59,62 @@ def assemble(tiles, height, width, world, stripe_rows, xp=np):
     return out
 
 
-class DistributedRenderer:
-    """Per-rank renderer + preallocated device tiles + the gather."""
+class TileGatherer:
+    """This rank's uint8 tile, the gather to rank 0 and the assembly of the frame there.
 
-    def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0):
+    Device-agnostic (``cuda`` with RCCL in production, ``cpu`` with gloo in the tests): whoever fills ``tile`` --
+    the HIP renderer or, in the CPU tests, the oracle -- calls ``gather()`` afterwards.
+    """
+
+    def __init__(self, width, height, device, group=None, stripe_rows=None):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
-        self.r = renderer
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.W, self.H = int(width), int(height)
-        self.flags = int(flags)
         self.stripe_rows = stripe_rows or stripe_rows_for(self.H, self.world)
         self.my_rows = rank_rows(self.H, self.world, self.rank, self.stripe_rows)
         self.max_rows = max_rows_per_rank(self.H, self.world, self.stripe_rows)
-        dev = torch.device("cuda", renderer.device)
-        self.tile = torch.zeros((self.max_rows, self.W, 3), dtype=torch.uint8, device=dev)
+        self.tile = torch.zeros((self.max_rows, self.W, 3), dtype=torch.uint8, device=device)
         self.gathered = None
         self.frame = None
         if self.rank == 0 and self.world > 1:
-            self.gathered = [torch.zeros_like(self.tile) for _ in range(self.world)]
-            self.index = [torch.as_tensor(rank_rows(self.H, self.world, r, self.stripe_rows), dtype=torch.long, device=dev)
-                          for r in range(self.world)]
-            self.frame = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=dev)
+            # the tiles land in one buffer [world, max_rows, W, 3]; image row y is row source_row[y] of its flat view,
+            # so the frame is assembled by ONE row gather instead of one scatter per rank
+            self.buffer = torch.zeros((self.world,) + tuple(self.tile.shape), dtype=torch.uint8, device=device)
+            self.gathered = [self.buffer[r] for r in range(self.world)]
+            self.source_row = torch.as_tensor(source_rows(self.H, self.world, self.stripe_rows, self.max_rows),
+                                              dtype=torch.long, device=device)
+            self.frame = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=device)
+
+    def gather(self):
+        """Frame (H, W, 3) uint8 on rank 0, None elsewhere; with one rank, the tile itself."""
+        if self.world == 1:
+            return self.tile[: len(self.my_rows)]
+        self.dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        self.torch.index_select(self.buffer.view(self.world * self.max_rows, self.W, 3), 0, self.source_row, out=self.frame)
+        return self.frame
+
+
+class DistributedRenderer(TileGatherer):
+    """Per-rank renderer writing into the preallocated device tile, then the gather."""
+
+    def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0):
+        import torch
+
+        super().__init__(width, height, torch.device("cuda", renderer.device), group, stripe_rows)
+        self.r = renderer
+        self.flags = int(flags)
 
     def render(self, seed=0):
         """Render this rank's stripes and gather; returns (frame on rank 0 else None, this rank's stats)."""
-        torch, dist = self.torch, self.dist
-        stream = torch.cuda.current_stream(self.tile.device).cuda_stream
+        stream = self.torch.cuda.current_stream(self.tile.device).cuda_stream
         stats = self.r.render_rows_device(self.W, self.H, 0, self.tile.data_ptr(), stream=stream, seed=seed,
                                           stripe_rows=self.stripe_rows, stripe_count=self.world, stripe_index=self.rank,
                                           flags=self.flags)
-        if self.world == 1:
-            return self.tile[: len(self.my_rows)], stats
-        dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
-        if self.rank != 0:
-            return None, stats
-        for r in range(self.world):
-            self.frame.index_copy_(0, self.index[r], self.gathered[r][: self.index[r].numel()])
-        return self.frame, stats
+        return self.gather(), stats

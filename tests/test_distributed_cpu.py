@@ -1,8 +1,8 @@
 """Row-stripe partition + gather, rehearsed on CPU with gloo (world_size 2 and 3).
 
 Each rank 'renders' its stripes with the CPU oracle (the GPU path is covered by the
-gpu tests), the uint8 tiles are gathered to rank 0 with torch.distributed exactly as
-raytracer_amd.distributed does on RCCL, and rank 0's assembled frame must equal the
+gpu tests) into the tile of raytracer_amd.distributed.TileGatherer -- the object the
+GPU path uses on RCCL -- which gathers the uint8 tiles to rank 0, and rank 0's assembled frame must equal the
 single-process frame bit for bit (the keyed jitter stream makes pixels independent
 of the partition).
 """
@@ -31,16 +31,17 @@ def _worker(rank, world, port, w, h, stripe_rows, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import rt_oracle
     sc = scene("transparency_v7")
-    rows = D.rank_rows(h, world, rank, stripe_rows)
-    mx = D.max_rows_per_rank(h, world, stripe_rows)
-    tile = torch.zeros((mx, w, 3), dtype=torch.uint8)
-    img, _ = rt_oracle.render_rows(sc, w, h, rows, seed=5, threads=1)
-    tile[: len(rows)] = torch.from_numpy(np.uint8(img))
-    gathered = [torch.zeros_like(tile) for _ in range(world)] if rank == 0 else None
-    dist.gather(tile, gathered, dst=0)
+    # the production gather / assembly object, on CPU tensors; the oracle stands in for the HIP renderer
+    tg = D.TileGatherer(w, h, torch.device("cpu"), stripe_rows=stripe_rows)
+    assert tg.my_rows == D.rank_rows(h, world, rank, stripe_rows)
+    for seed in (4, 5):   # two frames through the same buffers
+        img, _ = rt_oracle.render_rows(sc, w, h, tg.my_rows, seed=seed, threads=1)
+        tg.tile[: len(tg.my_rows)] = torch.from_numpy(np.uint8(img))
+        frame = tg.gather()
+    assert (frame is not None) == (rank == 0)
     if rank == 0:
-        frame = D.assemble([g.numpy() for g in gathered], h, w, world, stripe_rows)
-        np.save(out_path, frame)
+        assert np.array_equal(frame.numpy(), D.assemble([g.numpy() for g in tg.gathered], h, w, world, stripe_rows))
+        np.save(out_path, frame.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
