@@ -7,7 +7,7 @@ exit codes :169/:174): an image pair passes the *stochastic* check when
 tool has no per-pixel metric, so the *seeded* check is added here: the share of
 pixels whose three 8-bit channels all differ by at most 1 LSB (target >= 99.9 %).
 
-    python -m raytracer_amd.compare_images ref.png test.png [--save-diff d.png] [--lsb]
+    python -m raytracer_amd.compare_images ref.png test.png [--save-diff d.png] [--lsb] [--tiles 64]
 
 Exit codes: 0 match, 1 differ, 2 error.
 """
@@ -44,12 +44,31 @@ def metrics(ref_u8, test_u8):
     }
 
 
+def tile_psnr(ref_u8, test_u8, tile=64):
+    """PSNR of every ``tile`` x ``tile`` block (edge blocks are smaller): a localised defect that a whole-frame
+    PSNR averages away shows up as one bad tile.  Returns (grid of PSNR values, (row, col) of the worst tile)."""
+    a = np.asarray(ref_u8, dtype=np.float64) / 255.0
+    b = np.asarray(test_u8, dtype=np.float64) / 255.0
+    if a.shape != b.shape:
+        raise ValueError(f"Image shapes don't match: {a.shape} vs {b.shape}")
+    h, w = a.shape[:2]
+    ny, nx = (h + tile - 1) // tile, (w + tile - 1) // tile
+    grid = np.empty((ny, nx))
+    for ty in range(ny):
+        for tx in range(nx):
+            d = a[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile] - b[ty * tile:(ty + 1) * tile, tx * tile:(tx + 1) * tile]
+            mse = float(np.mean(d * d))
+            grid[ty, tx] = np.inf if mse == 0 else 10.0 * np.log10(1.0 / mse)
+    worst = np.unravel_index(int(np.argmin(grid)), grid.shape)
+    return grid, (int(worst[0]), int(worst[1]))
+
+
 def difference_map(ref_u8, test_u8, scale=10.0):
     d = np.abs(np.asarray(ref_u8, dtype=np.float64) - np.asarray(test_u8, dtype=np.float64)) / 255.0
     return np.uint8(np.clip(d * scale, 0.0, 1.0) * 255)
 
 
-def compare_images(ref_path, test_path, save_diff=None, verbose=True, seeded=False):
+def compare_images(ref_path, test_path, save_diff=None, verbose=True, seeded=False, tile=0):
     from PIL import Image
 
     ref = np.array(Image.open(ref_path))
@@ -62,6 +81,10 @@ def compare_images(ref_path, test_path, save_diff=None, verbose=True, seeded=Fal
         print(f"PSNR:      {m['psnr']:.2f} dB  (threshold: > {PSNR_THRESHOLD} dB)")
         print(f"<=1 LSB:   {100 * m['within_1lsb']:.4f} % of pixels  ({m['pixels_beyond_1lsb']} beyond, max diff {m['max_abs_diff']}; "
               f"seeded threshold: >= {100 * LSB_SHARE_THRESHOLD} %)")
+        if tile:
+            grid, (ty, tx) = tile_psnr(ref, test, tile)
+            m["worst_tile_psnr"] = float(grid[ty, tx])
+            print(f"Worst {tile}x{tile} tile: {grid[ty, tx]:.2f} dB at rows {ty * tile}.., columns {tx * tile}..")
         print("PASS" if m["pass"] else "FAIL")
     if save_diff:
         Image.fromarray(difference_map(ref, test)).save(save_diff)
@@ -75,9 +98,10 @@ def main(argv=None):
     ap.add_argument("--save-diff", metavar="PATH")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--lsb", action="store_true", help="judge by the share of pixels within 1 LSB (seeded renders)")
+    ap.add_argument("--tiles", type=int, default=0, metavar="SIZE", help="also report the worst SIZE x SIZE tile's PSNR")
     a = ap.parse_args(argv)
     try:
-        r = compare_images(a.reference, a.test, a.save_diff, not a.quiet, a.lsb)
+        r = compare_images(a.reference, a.test, a.save_diff, not a.quiet, a.lsb, a.tiles)
     except Exception as e:  # noqa: BLE001
         if not a.quiet:
             print(f"Error: {e}", file=sys.stderr)

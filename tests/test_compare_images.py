@@ -53,3 +53,16 @@ def test_cli_exit_codes(tmp_path):
         with pytest.raises(SystemExit) as e:
             CI.main(args)
         assert e.value.code == code, args
+
+
+def test_tile_psnr_localises_a_defect():
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, size=(100, 150, 3), dtype=np.uint8)
+    b = a.copy()
+    b[70:90, 130:150] = 255 - b[70:90, 130:150]          # one damaged corner block
+    grid, worst = CI.tile_psnr(a, b, tile=64)
+    assert grid.shape == (2, 3) and worst == (1, 2)
+    assert np.isinf(grid[0, 0]) and grid[1, 2] < 15.0
+    assert CI.metrics(a, b)["psnr"] > grid[1, 2]          # the whole-frame figure averages the defect away
+    with pytest.raises(ValueError):
+        CI.tile_psnr(a, b[:50])
