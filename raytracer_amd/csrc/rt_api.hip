@@ -40,6 +40,7 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
+constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
 constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 
@@ -74,6 +75,10 @@ struct rt_handle {
     double* d_accum = nullptr;
     unsigned long long* d_counters = nullptr;  // CNT_N statistics words, directly followed by d_qcounts (one memset per band)
     uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
+    // uniform grid over the bounded surfaces (large scenes)
+    SceneGrid grid{};
+    uint32_t* d_grid_mem = nullptr;
+    int grid_override = -1;          // RT_GRID: -1 automatic (more than kGridMinSurfaces surfaces), 0 never, 1 always
     // run-to-completion tail of the ray tree (k_trace_tail)
     bool both_children = false;      // some material spawns a reflection and a transparency child
     RayQueue stack{};                // parked children, [level][thread]
@@ -183,7 +188,7 @@ struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_re
 // pool frame, 0.55 against 0.89 ms on the 1080p transparency scene).  The choice never changes
 // the image.
 int choose_tail_depth(const rt_handle* h, int depths) {
-    if (h->S > RT_SURF_TILE || depths < 2) return depths;
+    if ((h->S > RT_SURF_TILE && !h->grid.cell_start) || depths < 2) return depths;
     if (h->tail_override == 0) return depths;
     if (h->tail_override > 0) return std::min(h->tail_override, depths);
     return 0;
@@ -245,7 +250,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     if (tail_from < depths) { int rc = ensure_tail_stack(h, tail_blocks); if (rc != RT_OK) return rc; }
     for (int d = 0; d < depths && d <= tail_from; ++d) {
         TraceArgs ta{};
-        ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat;
+        ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat; ta.grid = h->grid;
         // every depth has its own counter word (zeroed with the others, once per band): no memset per depth
         ta.in = h->rq[d & 1]; ta.out = h->rq[(d + 1) & 1];
         ta.in.count = h->d_qcounts + 8 + d; ta.out.count = h->d_qcounts + 8 + d + 1;
@@ -264,7 +269,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventRecord(h->ev[1], st));
     if (!debug) {
         ShadeArgs sa{};
-        sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq;
+        sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq; sa.grid = h->grid;
         sa.accum = h->d_accum; sa.npix = pixels; sa.counters = h->d_counters;
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
@@ -351,6 +356,86 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     return RT_OK;
 }
 
+// Uniform grid over the bounding boxes of spheres and boxes (planes go to the global list).  About four
+// cells per surface, cubic cells; a surface is listed in every cell its box touches after growing it by
+// 1e-6 of the scene extent, which makes the lists robust against rounding at cell borders in the walks.
+int build_grid(rt_handle* h, const std::vector<SurfD>& sd, int S) {
+    if (h->d_grid_mem) (void)hipFree(h->d_grid_mem);
+    h->d_grid_mem = nullptr;
+    h->grid = SceneGrid{};
+    const bool want = h->grid_override == 1 || (h->grid_override != 0 && S > kGridMinSurfaces);
+    if (!want) return RT_OK;
+    std::vector<uint32_t> global_items;
+    std::vector<int> bounded;
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto box_of = [&](const SurfD& a, double* bl, double* bh) {
+        if (a.type == RT_SURF_SPHERE) { const double r = std::fabs(a.d[3]); for (int k = 0; k < 3; ++k) { bl[k] = a.d[k] - r; bh[k] = a.d[k] + r; } }
+        else for (int k = 0; k < 3; ++k) { bl[k] = std::min(a.d[k], a.d[3 + k]); bh[k] = std::max(a.d[k], a.d[3 + k]); }
+    };
+    for (int s = 0; s < S; ++s) {
+        if (sd[s].type == RT_SURF_PLANE) { global_items.push_back((uint32_t)s); continue; }
+        double bl[3], bh[3];
+        box_of(sd[s], bl, bh);
+        bool finite = true;
+        for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(bl[k]) && std::isfinite(bh[k]);
+        if (!finite) { global_items.push_back((uint32_t)s); continue; }
+        bounded.push_back(s);
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], bl[k]); hi[k] = std::max(hi[k], bh[k]); }
+    }
+    if (bounded.empty()) return RT_OK;
+    double ext[3], max_ext = 0;
+    for (int k = 0; k < 3; ++k) { ext[k] = hi[k] - lo[k]; max_ext = std::max(max_ext, ext[k]); }
+    if (!(max_ext > 0)) max_ext = 1.0;
+    const double grow = 1e-6 * max_ext + 1e-9;
+    for (int k = 0; k < 3; ++k) { lo[k] -= 2 * grow; hi[k] += 2 * grow; ext[k] = hi[k] - lo[k]; }
+    const double target = std::min(4.0 * (double)bounded.size(), 2097152.0);
+    const double edge = std::cbrt(ext[0] * ext[1] * ext[2] / target);
+    SceneGrid g{};
+    size_t cells = 1;
+    for (int k = 0; k < 3; ++k) {
+        int n = edge > 0 ? (int)std::ceil(ext[k] / edge) : 1;
+        n = std::max(1, std::min(n, 512));
+        g.n[k] = n; g.lo[k] = lo[k]; g.cell[k] = ext[k] / n; g.inv_cell[k] = 1.0 / g.cell[k];
+        cells *= (size_t)n;
+    }
+    auto range_of = [&](int s, int* c0, int* c1) {
+        double bl[3], bh[3];
+        box_of(sd[s], bl, bh);
+        for (int k = 0; k < 3; ++k) {
+            c0[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((bl[k] - grow - g.lo[k]) * g.inv_cell[k])));
+            c1[k] = std::max(0, std::min(g.n[k] - 1, (int)std::floor((bh[k] + grow - g.lo[k]) * g.inv_cell[k])));
+        }
+    };
+    std::vector<uint32_t> start(cells + 1, 0);
+    for (int s : bounded) {
+        int c0[3], c1[3];
+        range_of(s, c0, c1);
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
+            start[((size_t)z * g.n[1] + y) * g.n[0] + x + 1] += 1;
+    }
+    for (size_t c = 0; c < cells; ++c) start[c + 1] += start[c];
+    std::vector<uint32_t> items(std::max<size_t>(start[cells], 1)), fill(start.begin(), start.end() - 1);
+    for (int s : bounded) {   // ascending surface index => every cell list is ascending
+        int c0[3], c1[3];
+        range_of(s, c0, c1);
+        for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
+            items[fill[((size_t)z * g.n[1] + y) * g.n[0] + x]++] = (uint32_t)s;
+    }
+    const size_t words = start.size() + items.size() + std::max<size_t>(global_items.size(), 1);
+    HIP_TRY(h, hipMalloc(&h->d_grid_mem, words * sizeof(uint32_t)));
+    uint32_t* p = h->d_grid_mem;
+    HIP_TRY(h, hipMemcpy(p, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g.cell_start = p; p += start.size();
+    HIP_TRY(h, hipMemcpy(p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g.items = p; p += items.size();
+    if (!global_items.empty())
+        HIP_TRY(h, hipMemcpy(p, global_items.data(), global_items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g.global_items = p;
+    g.n_global = (int)global_items.size();
+    h->grid = g;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -367,6 +452,7 @@ int rt_create(int device, rt_handle** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
     // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d on (default: from the camera rays)
     if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
+    if (const char* e = std::getenv("RT_GRID")) h->grid_override = std::atoi(e);  // test hook: force the grid on / off
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
         long v = std::atol(e);
         if (v > 0) h->max_band_pixels = (size_t)v;
@@ -384,7 +470,7 @@ void rt_destroy(rt_handle* h) {
     (void)hipSetDevice(h->device);
     free_frame_buffers(h);
     for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_counters,
-                    (void*)h->stack_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
+                    (void*)h->stack_mem, (void*)h->d_grid_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
@@ -504,6 +590,8 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_surff, sf.data(), sizeof(SurfF) * sf.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_mat, mats.data(), sizeof(MatF) * mats.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_light, lights.data(), sizeof(LightF) * lights.size(), hipMemcpyHostToDevice));
+    int rc = build_grid(h, sd, S);
+    if (rc != RT_OK) return rc;
     h->S = S; h->M = M; h->L = L; h->N = d->n_shadow; h->R = d->max_rec;
     for (int c = 0; c < 3; ++c) h->bg[c] = (float)d->background[c];
     h->cam = cam;

@@ -36,6 +36,20 @@ struct __attribute__((aligned(16))) SurfF {
     int32_t pad;
 };
 
+// ---- uniform grid over the bounded surfaces (spheres, boxes), built on upload for large scenes ----
+// Cell (ix, iy, iz) lists, in ascending order, the surfaces whose slightly inflated bounding box
+// touches it: items[cell_start[c] .. cell_start[c + 1]) with c = (iz * n[1] + iy) * n[0] + ix.
+// Unbounded surfaces (planes) are in global_items and tested for every ray.  cell_start == nullptr:
+// no grid, every ray is tested against every surface.
+struct SceneGrid {
+    double lo[3], cell[3], inv_cell[3];
+    int32_t n[3];
+    int32_t n_global;
+    const uint32_t* cell_start;
+    const uint32_t* items;
+    const uint32_t* global_items;
+};
+
 struct MatF {
     float kd[3], ks[3], kr[3];
     float shin, transp;
@@ -135,6 +149,7 @@ struct TraceArgs {
     CameraD cam;
     const SurfD* surf;
     const MatF* mat;
+    SceneGrid grid;
     RayQueue in, out;
     ShadeQueue shade;
     HitDebug dbg;          // capacity 0 = off
@@ -146,7 +161,7 @@ struct TraceArgs {
     uint32_t stack_levels; // slots per thread (0: the scene has no material with both children)
 };
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
-// follows every ray of a.in (depth a.depth >= 1) to the recursion limit; n_surfaces must fit one LDS tile (RT_SURF_TILE)
+// follows every ray of a.in (or every camera ray when a.depth == 0) to the recursion limit; needs a.grid, or n_surfaces <= RT_SURF_TILE
 void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s);
 
 enum { SHADE_AUTO = 0, SHADE_GENERAL = 1 };
@@ -164,6 +179,7 @@ struct ShadeArgs {
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;
+    SceneGrid grid;      // used by the any-size kernel
     ShadeQueue q;
     double* accum;       // planar [3][npix]
     size_t npix;

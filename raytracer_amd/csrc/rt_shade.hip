@@ -192,9 +192,103 @@ __device__ __forceinline__ bool load_chunk(const ShadeQueue& q, uint32_t base, u
     return true;
 }
 
+// Light factor of one shadow ray (product of the transparencies of the surfaces it crosses,
+// ray_tracer.py:42-46 / :70-78) for scenes of any size.  BATCH picks the multi-sample semantics.
+// Without a grid every surface is tested.  With one, the planes are tested first and the segment then
+// walks its cells (the walk itself in float64; the surface tests stay FP32); a surface listed in several
+// cells must count once: the cells that list a surface form one contiguous run along a ray, so a surface
+// also present in the previously visited cell has been counted already.
+template <bool BATCH>
+__device__ __forceinline__ bool surface_blocks(const SurfF& sf, f3 P, f3 w, float dist, bool own, f3 nrm, uint32_t flags) {
+    if (BATCH) {
+        if (sf.type == RT_SURF_SPHERE) return sphere_blocks_b(sf, P, w, dist, own, flags);
+        if (sf.type == RT_SURF_PLANE) return plane_blocks_b(sf, P, w, dist, own);
+        return box_blocks_b(sf, P, w, dist, own, nrm);
+    }
+    if (sf.type == RT_SURF_SPHERE) return sphere_blocks_a(sf, P, w, dist, own, flags);
+    if (sf.type == RT_SURF_PLANE) return plane_blocks_a(sf, P, w, dist, own);
+    return box_blocks_a(sf, P, w, dist, own, nrm, flags);
+}
+
+template <bool BATCH>
+__device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, float dist, int own_id, f3 nrm, uint32_t flags) {
+    const SceneGrid& g = a.grid;
+    float f = 1.f;
+    if (!g.cell_start) {
+        const int S = a.fp.n_surfaces;
+        for (int s = 0; s < S; ++s) {
+            const SurfF sf = a.surf[s];
+            f = surface_blocks<BATCH>(sf, P, w, dist, s == own_id, nrm, flags) ? f * sf.transp : f;
+        }
+        return f;
+    }
+    if (own_id >= 0) {  // the hit's own surface, by rule, once
+        const SurfF sf = a.surf[own_id];
+        f = surface_blocks<BATCH>(sf, P, w, dist, true, nrm, flags) ? f * sf.transp : f;
+    }
+    for (int k = 0; k < g.n_global; ++k) {
+        const int j = (int)g.global_items[k];
+        if (j == own_id) continue;
+        const SurfF sf = a.surf[j];
+        f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
+    }
+    if (f == 0.f) return f;
+    const double oo[3] = {(double)P.x, (double)P.y, (double)P.z}, dd[3] = {(double)w.x, (double)w.y, (double)w.z};
+    double t0 = 0.0, t1 = (double)dist;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const double lo = g.lo[ax], hi = g.lo[ax] + g.cell[ax] * (double)g.n[ax];
+        if (dd[ax] == 0.0) { if (oo[ax] < lo || oo[ax] > hi) return f; }
+        else {
+            double ta = (lo - oo[ax]) / dd[ax], tb = (hi - oo[ax]) / dd[ax];
+            if (ta > tb) { const double sw = ta; ta = tb; tb = sw; }
+            t0 = ta > t0 ? ta : t0; t1 = tb < t1 ? tb : t1;
+        }
+    }
+    if (t0 > t1) return f;
+    int idx[3], step[3];
+    double t_max[3], t_delta[3];
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const double p = oo[ax] + dd[ax] * t0;
+        int i = (int)floor((p - g.lo[ax]) * g.inv_cell[ax]);
+        i = i < 0 ? 0 : (i >= g.n[ax] ? g.n[ax] - 1 : i);
+        idx[ax] = i;
+        step[ax] = dd[ax] > 0.0 ? 1 : -1;
+        if (dd[ax] == 0.0) { t_max[ax] = INFINITY; t_delta[ax] = INFINITY; }
+        else {
+            t_max[ax] = (g.lo[ax] + g.cell[ax] * (double)(i + (dd[ax] > 0.0 ? 1 : 0)) - oo[ax]) / dd[ax];
+            t_delta[ax] = g.cell[ax] / fabs(dd[ax]);
+        }
+    }
+    uint32_t p0 = 0, p1 = 0;  // item range of the previously visited cell
+    const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
+    for (int it = 0; it < max_steps; ++it) {
+        const uint32_t c = (uint32_t)((idx[2] * g.n[1] + idx[1]) * g.n[0] + idx[0]);
+        const uint32_t k0 = g.cell_start[c], k1 = g.cell_start[c + 1];
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t j = g.items[k];
+            if ((int)j == own_id) continue;
+            bool seen = false;
+            for (uint32_t q = p0; q < p1; ++q) seen = seen || g.items[q] == j;
+            if (seen) continue;
+            const SurfF sf = a.surf[j];
+            f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
+        }
+        if (f == 0.f) return f;
+        p0 = k0; p1 = k1;
+        const int ax = t_max[0] <= t_max[1] ? (t_max[0] <= t_max[2] ? 0 : 2) : (t_max[1] <= t_max[2] ? 1 : 2);
+        if (t_max[ax] > t1) return f;   // the segment ends (or leaves the grid) inside this cell
+        idx[ax] += step[ax];
+        if (idx[ax] < 0 || idx[ax] >= g.n[ax]) return f;
+        t_max[ax] += t_delta[ax];
+    }
+    return f;
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
-    const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
+    const int L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
@@ -222,17 +316,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             if (lt.point_path) {
                 // ---- one ray to the light centre (ray_tracer.py:36-48)
                 const float dist = lc2 * linv;
-                float f = 1.f;
-                for (int s = 0; s < S; ++s) {
-                    const SurfF sf = a.surf[s];
-                    const bool own = s == own_id;
-                    bool blk;
-                    if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
-                    else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
-                    else blk = box_blocks_a(sf, P, ldir, dist, own, nrm, flags);
-                    f = blk ? f * sf.transp : f;
-                }
-                ratio = f;
+                ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags);
             } else {
                 // ---- light basis (light.py:24-30) and the N x N grid (light.py:51-63)
                 const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
@@ -252,17 +336,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         const float dinv = __frsqrt_rn(d2);
                         const f3 w = sv * dinv;
                         const float dist = d2 * dinv;
-                        float f = 1.f;
-                        for (int s = 0; s < S; ++s) {
-                            const SurfF sf = a.surf[s];
-                            const bool own = s == own_id;
-                            bool blk;
-                            if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_b(sf, P, w, dist, own, flags);
-                            else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_b(sf, P, w, dist, own);
-                            else blk = box_blocks_b(sf, P, w, dist, own, nrm);
-                            f = blk ? f * sf.transp : f;
-                        }
-                        sum += f;
+                        sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags);
                     }
                 }
                 ratio = sum * inv_n2;

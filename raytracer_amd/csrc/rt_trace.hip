@@ -132,6 +132,62 @@ __device__ __forceinline__ void nearest_in_tile(const SurfD* tile, int ns, int s
     }
 }
 
+// The same query through the uniform grid.  Candidates may arrive in any order and more than once, so
+// the file-order rule is explicit: smaller t wins, equal t goes to the lower surface index -- exactly
+// what the strict '<' of the ascending loop yields.  The walk stops once the best hit lies before the
+// exit of the current cell: every surface that could be hit earlier, or at the same t, touches a cell
+// already visited (cell lists are built from inflated boxes, which covers rounding at cell borders).
+__device__ __forceinline__ void grid_candidate(const SurfD& sf, int j, d3 o, d3 d, double& best, int& bs, int& bcode) {
+    double t; int code = 0; bool hit;
+    if (sf.type == RT_SURF_SPHERE) hit = sphere_t(sf, o, d, t);
+    else if (sf.type == RT_SURF_PLANE) hit = plane_t(sf, o, d, t);
+    else hit = box_t(sf, o, d, t, code);
+    if (hit && t > RT_EPS && (t < best || (t == best && j < bs))) { best = t; bs = j; bcode = code; }
+}
+__device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD* surf, d3 o, d3 d, double& best, int& bs, int& bcode) {
+    for (int k = 0; k < g.n_global; ++k) { const int j = (int)g.global_items[k]; grid_candidate(surf[j], j, o, d, best, bs, bcode); }
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+    double t0 = 0.0, t1 = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = g.lo[a], hi = g.lo[a] + g.cell[a] * (double)g.n[a];
+        if (dd[a] == 0.0) { if (oo[a] < lo || oo[a] > hi) return; }
+        else {
+            double ta = (lo - oo[a]) / dd[a], tb = (hi - oo[a]) / dd[a];
+            if (ta > tb) { const double w = ta; ta = tb; tb = w; }
+            t0 = ta > t0 ? ta : t0; t1 = tb < t1 ? tb : t1;
+        }
+    }
+    if (t0 > t1 || best < t0) return;
+    int idx[3], step[3];
+    double t_max[3], t_delta[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double p = oo[a] + dd[a] * t0;
+        int i = (int)floor((p - g.lo[a]) * g.inv_cell[a]);
+        i = i < 0 ? 0 : (i >= g.n[a] ? g.n[a] - 1 : i);
+        idx[a] = i;
+        step[a] = dd[a] > 0.0 ? 1 : -1;
+        if (dd[a] == 0.0) { t_max[a] = INFINITY; t_delta[a] = INFINITY; }
+        else {
+            t_max[a] = (g.lo[a] + g.cell[a] * (double)(i + (dd[a] > 0.0 ? 1 : 0)) - oo[a]) / dd[a];
+            t_delta[a] = g.cell[a] / fabs(dd[a]);
+        }
+    }
+    const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
+    for (int it = 0; it < max_steps; ++it) {
+        const uint32_t c = (uint32_t)((idx[2] * g.n[1] + idx[1]) * g.n[0] + idx[0]);
+        const uint32_t k1 = g.cell_start[c + 1];
+        for (uint32_t k = g.cell_start[c]; k < k1; ++k) { const int j = (int)g.items[k]; grid_candidate(surf[j], j, o, d, best, bs, bcode); }
+        const int ax = t_max[0] <= t_max[1] ? (t_max[0] <= t_max[2] ? 0 : 2) : (t_max[1] <= t_max[2] ? 1 : 2);
+        const double t_exit = t_max[ax];
+        if (best < t_exit - 1e-9 * (1.0 + fabs(t_exit))) return;
+        idx[ax] += step[ax];
+        if (idx[ax] < 0 || idx[ax] >= g.n[ax]) return;
+        t_max[ax] += t_delta[ax];
+    }
+}
+
 // hit point, normal and own-surface flags of the winning surface
 struct HitFrame { d3 P, n; uint32_t flags; int mat; };
 __device__ __forceinline__ HitFrame hit_frame(const SurfD& sf, d3 o, d3 d, double best, int bcode) {
@@ -234,7 +290,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
 
-    const bool single_tile = S <= SURF_TILE;
+    const bool use_grid = a.grid.cell_start != nullptr;  // lanes walk their own cells: surfaces come from global memory (L2)
+    const bool single_tile = S <= SURF_TILE && !use_grid;
     if (single_tile) {
         // the whole surface list is staged once per workgroup
         const double* src = (const double*)a.surf;
@@ -282,7 +339,8 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         // ---- find_nearest_intersection (scene_settings.py:31-46): file order, strict '<' ----
         double best = INFINITY;
         int bs = -1, bcode = 0;
-        for (int s0 = 0; s0 < S; s0 += SURF_TILE) {
+        if (use_grid && active) nearest_in_grid(a.grid, a.surf, o, d, best, bs, bcode);
+        for (int s0 = 0; s0 < S && !use_grid; s0 += SURF_TILE) {
             int ns = S - s0 < SURF_TILE ? S - s0 : SURF_TILE;
             if (!single_tile) {
                 __syncthreads();
@@ -409,7 +467,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 // level, laid out [level][thread] so a wave's accesses stay contiguous).  All rays of a lane's
 // subtree belong to one pixel.  The workgroup steps through the levels together so that shade
 // records are reserved with ONE atomic per workgroup and step (per-wave reservations would
-// serialise on the counter word).  Needs the whole surface list in one LDS tile.
+// serialise on the counter word).  Needs the whole surface list in one LDS tile, or the grid.
 // ---------------------------------------------------------------------------------------
 #define TAIL_BLOCK RT_TAIL_BLOCK
 template <bool PRIMARY>
@@ -421,7 +479,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     uint32_t count;
     if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
-    {
+    const bool use_grid = a.grid.cell_start != nullptr;
+    if (!use_grid) {
         const double* src = (const double*)a.surf;
         double* dst = (double*)tile;
         for (int i = threadIdx.x; i < S * 8; i += TAIL_BLOCK) dst[i] = src[i];
@@ -459,12 +518,13 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             int bs = -1, bcode = 0;
             if (have) {
                 if (PRIMARY && depth == 0) n_primary += 1; else n_traced += 1;
-                nearest_in_tile(tile, S, 0, o, d, best, bs, bcode);
+                if (use_grid) nearest_in_grid(a.grid, a.surf, o, d, best, bs, bcode);
+                else nearest_in_tile(tile, S, 0, o, d, best, bs, bcode);
             }
             const bool hit = have && bs >= 0;
             HitFrame f;
             f.P = D3(0, 0, 0); f.n = D3(0, 0, 0); f.flags = 0; f.mat = 0;
-            if (hit) f = hit_frame(tile[bs], o, d, best, bcode);
+            if (hit) f = hit_frame(use_grid ? a.surf[bs] : tile[bs], o, d, best, bcode);
             const MatF m = a.mat[f.mat];
             if (a.dbg.capacity) {
                 uint32_t slot = wave_append(a.dbg.count, have);
