@@ -405,6 +405,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 #define SMALL_MAX 8
 #define NSLOT (SMALL_MAX + 1)  // + one slot for the hit's own sphere
 #define KMAX 8                 // linear tests the compact sample loop keeps in registers
+#define NBMAX 3                // boxes it can test beside them
 #define PLANE_SCALE 1152921504606846976.0f  // 2^60
 
 // intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light
@@ -430,9 +431,38 @@ __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, c
 // root is taken.  All-opaque scenes only need "any entry blocks" = that sign for the maximum
 // of the lin_e, shifted into a bit mask and counted once per row.
 // Returns the sum of the light factors of the N*N samples.
-template <int K, bool ALL_OPAQUE>
+//
+// NB > 0 adds boxes, tested per sample with slabs on the unnormalised sample direction
+// sv = lrel + ur*right + vr*up (the sample sits at parameter 1): entry = max of the per-axis minima,
+// exit = min of the maxima, blocked  <=>  entry <= exit, exit >= 0 and entry < 1, i.e.
+// min(exit - entry, exit, 1 - entry) >= 0; the three reciprocals are shared by all boxes.  Only boxes
+// the hit point keeps clear of are handled here, so the 1e-6 window of cube.py:167-168 cannot bind.
+struct BoxSet {
+    f3 lrel, right, up;
+    float lo[NBMAX][3], hi[NBMAX][3];  // corners relative to the hit point
+    float tr[NBMAX];
+};
+template <int NB>
+__device__ __forceinline__ void box_values(const BoxSet& bx, float ur, float vr, float (&val)[NB > 0 ? NB : 1]) {
+    const float sx = fmaf(vr, bx.up.x, fmaf(ur, bx.right.x, bx.lrel.x));
+    const float sy = fmaf(vr, bx.up.y, fmaf(ur, bx.right.y, bx.lrel.y));
+    const float sz = fmaf(vr, bx.up.z, fmaf(ur, bx.right.z, bx.lrel.z));
+    const float ix = __builtin_amdgcn_rcpf(sx), iy = __builtin_amdgcn_rcpf(sy), iz = __builtin_amdgcn_rcpf(sz);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float x1 = bx.lo[b][0] * ix, x2 = bx.hi[b][0] * ix;
+        const float y1 = bx.lo[b][1] * iy, y2 = bx.hi[b][1] * iy;
+        const float z1 = bx.lo[b][2] * iz, z2 = bx.hi[b][2] * iz;
+        const float t_in = fmaxf(fmaxf(fminf(x1, x2), fminf(y1, y2)), fminf(z1, z2));
+        const float t_out = fminf(fminf(fmaxf(x1, x2), fmaxf(y1, y2)), fmaxf(z1, z2));
+        val[b] = fminf(fminf(t_out - t_in, t_out), 1.0f - t_in);
+    }
+}
+
+template <int K, int NB, bool ALL_OPAQUE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
-                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX]) {
+                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX],
+                                                 const BoxSet& bx) {
     if (ALL_OPAQUE) {
         // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
         // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
@@ -444,6 +474,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         uint32_t open_samples = 0;
         // decided(i0,i1,j0,j1): 0 = undecided for some lane, 1 = decided for the whole wave (adds the open count)
         auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
+            if (NB > 0) return false;  // boxes have no tile bound here: every sample is tested
             const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
             const float va = fmaf((float)j0, cell, koff), vb = fmaf((float)j1, cell, koff);
             const float u2lo = ua * ub <= 0.f ? 0.f : fminf(ua * ua, ub * ub), u2hi = fmaxf(ua * ua, ub * ub);
@@ -485,12 +516,19 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                                 // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
                                 const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
                                 const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
-                                float vmax = fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0]));
+                                float vmax = K > 0 ? fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0])) : -INFINITY;
 #pragma unroll
                                 for (int e = 1; e < K; ++e)
                                     vmax = __builtin_fmaxf(vmax, fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e])));
-                                // sign bit set <=> no entry blocks this sample
-                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(fmaf(vmax, fabsf(vmax), -len2)), 31);
+                                float res = fmaf(vmax, fabsf(vmax), -len2);
+                                if (NB > 0) {
+                                    float val[NB > 0 ? NB : 1];
+                                    box_values<NB>(bx, ur, vr, val);
+#pragma unroll
+                                    for (int b = 0; b < NB; ++b) res = __builtin_fmaxf(res, val[b]);
+                                }
+                                // sign bit set <=> nothing blocks this sample
+                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res), 31);
                             }
                             open_samples += (uint32_t)__popc(mask);
                         }
@@ -515,6 +553,12 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                     const float lin = fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]));
                     f = fmaf(lin, fabsf(lin), -len2) >= 0.f ? f * tr[e] : f;
                 }
+                if (NB > 0) {
+                    float val[NB > 0 ? NB : 1];
+                    box_values<NB>(bx, ur, vr, val);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) f = val[b] >= 0.f ? f * bx.tr[b] : f;
+                }
                 sum += f;
             }
         }
@@ -522,8 +566,8 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     }
 }
 
-template <bool ALL_OPAQUE>
-__global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
+template <bool ALL_OPAQUE, bool HAS_BOX>
+__global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
@@ -600,7 +644,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
                 float A[NSLOT], B[NSLOT], C[NSLOT];
                 bool gen = false;
-                uint32_t lin = 0, reach_bits = 0;
+                uint32_t lin = 0, reach_bits = 0, box_bits = 0;
 #pragma unroll
                 for (int j = 0; j < SMALL_MAX; ++j) {
                     A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
@@ -653,7 +697,16 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                                 const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
                                 const f3 q = oc + lrel * t;
                                 const float reach = sf.c.w + rho;
-                                if (!(dot(q, q) > reach * reach * 1.0002f)) { gen = true; reach_bits |= 1u << j; }
+                                if (!(dot(q, q) > reach * reach * 1.0002f)) {
+                                    reach_bits |= 1u << j;
+                                    // clear of the box by more than rounding: the slab test of the sample loop is exact
+                                    const float gx = fmaxf(fmaxf(sf.a.x - P.x, P.x - sf.b.x), 0.f);
+                                    const float gy = fmaxf(fmaxf(sf.a.y - P.y, P.y - sf.b.y), 0.f);
+                                    const float gz = fmaxf(fmaxf(sf.a.z - P.z, P.z - sf.b.z), 0.f);
+                                    const float clear2 = fmaf(gx, gx, fmaf(gy, gy, gz * gz));
+                                    if (HAS_BOX && clear2 > 1e-6f * sf.c.w * sf.c.w) box_bits |= 1u << j;
+                                    else gen = true;
+                                }
                             }
                         }
                     }
@@ -675,15 +728,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                 for (int s = 0; s < NSLOT; ++s)
                     if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
                 const int k = __popc(cand);
-                defer = __any(gen) || k > KMAX;
+                uint32_t bcand = 0;
+                if (HAS_BOX) {
+#pragma unroll
+                    for (int s = 0; s < SMALL_MAX; ++s)
+                        if (STYPE(s) == RT_SURF_BOX && __ballot((box_bits >> s) & 1u)) bcand |= 1u << s;
+                }
+                const int nb = __popc(bcand);
+                defer = __any(gen) || k > KMAX || nb > NBMAX;
                 if (defer) {
 #pragma unroll
                     for (int s = 0; s < SMALL_MAX; ++s)
                         if (__ballot((reach_bits >> s) & 1u)) defer_mask |= 1u << s;
                 }
                 if (!defer) {
-                    wl_n[k <= 4 ? k : 4] += 1;
-                    if (k > 0) {
+                    wl_n[k + nb <= 4 ? k + nb : 4] += 1;
+                    if (k + nb > 0) {
                         // ---- compact the wave's candidate tests into register triples
                         float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
                         uint32_t rem = cand;
@@ -704,16 +764,54 @@ __global__ __launch_bounds__(SHADE_BLOCK, 4) void k_shade_fast(ShadeArgs a) {
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
                         const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
                         const float koff = -0.5f * lt.radius;
+                        BoxSet bx;
+                        if (HAS_BOX && nb > 0) {
+                            bx.lrel = lrel; bx.right = right; bx.up = up;
+                            uint32_t brem = bcand;
+#pragma unroll
+                            for (int b = 0; b < NBMAX; ++b) {
+                                const int sl = brem ? (int)__builtin_ctz(brem) : 0;  // wave-uniform surface index
+                                // per lane: only a box this lane found in reach and keeps clear of (its own box and
+                                // boxes out of reach stay inert: an empty box far away)
+                                const bool used = brem != 0u && ((box_bits >> sl) & 1u);
+                                brem &= brem - 1u;
+                                const SurfF sf = a.surf[sl];
+                                bx.lo[b][0] = used ? sf.a.x - P.x : 1e30f; bx.hi[b][0] = used ? sf.b.x - P.x : 1e30f;
+                                bx.lo[b][1] = used ? sf.a.y - P.y : 1e30f; bx.hi[b][1] = used ? sf.b.y - P.y : 1e30f;
+                                bx.lo[b][2] = used ? sf.a.z - P.z : 1e30f; bx.hi[b][2] = used ? sf.b.z - P.z : 1e30f;
+                                bx.tr[b] = used ? sf.transp : 1.f;
+                            }
+                        }
                         float sum;
-                        switch (k) {
-                            case 1: sum = compact_samples<1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 2: sum = compact_samples<2, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 3: sum = compact_samples<3, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 4: sum = compact_samples<4, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 5: sum = compact_samples<5, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 6: sum = compact_samples<6, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            case 7: sum = compact_samples<7, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
-                            default: sum = compact_samples<8, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd); break;
+                        if (!HAS_BOX || nb == 0) {
+                            switch (k) {
+                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                            }
+                        } else {
+                            // boxes: linear rows rounded up to 0 / 2 / 4 / 8 (spare rows are inert), boxes to 1 or NBMAX
+                            const int kk = k == 0 ? 0 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
+                            if (nb == 1) {
+                                switch (kk) {
+                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                }
+                            } else {
+                                switch (kk) {
+                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                }
+                            }
                         }
                         ratio = sum * inv_n2;
                     }
@@ -949,8 +1047,13 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
         return;
     }
-    if (a.all_opaque) hipLaunchKernelGGL(k_shade_fast<true>, g, b, 0, s, a);
-    else hipLaunchKernelGGL(k_shade_fast<false>, g, b, 0, s, a);
+    if (a.has_box) {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_fast<false, true>), g, b, 0, s, a);
+    } else {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_fast<false, false>), g, b, 0, s, a);
+    }
     if (a.has_box) {
         if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<true, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_shade_deferred<true, false>), g, b, 0, s, a);

@@ -159,32 +159,31 @@ __device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD*
         }
     }
     if (t0 > t1 || best < t0) return;
-    int idx[3], step[3];
-    double t_max[3], t_delta[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
+    // per-axis state in scalars (a dynamically indexed array would live in scratch memory)
+    int ix, iy, iz, sx, sy, sz;
+    double mx, my, mz, ex, ey, ez;
+    auto setup = [&](int a, int& i, int& st, double& tm, double& td) {
         const double p = oo[a] + dd[a] * t0;
-        int i = (int)floor((p - g.lo[a]) * g.inv_cell[a]);
+        i = (int)floor((p - g.lo[a]) * g.inv_cell[a]);
         i = i < 0 ? 0 : (i >= g.n[a] ? g.n[a] - 1 : i);
-        idx[a] = i;
-        step[a] = dd[a] > 0.0 ? 1 : -1;
-        if (dd[a] == 0.0) { t_max[a] = INFINITY; t_delta[a] = INFINITY; }
+        st = dd[a] > 0.0 ? 1 : -1;
+        if (dd[a] == 0.0) { tm = INFINITY; td = INFINITY; }
         else {
-            t_max[a] = (g.lo[a] + g.cell[a] * (double)(i + (dd[a] > 0.0 ? 1 : 0)) - oo[a]) / dd[a];
-            t_delta[a] = g.cell[a] / fabs(dd[a]);
+            tm = (g.lo[a] + g.cell[a] * (double)(i + (dd[a] > 0.0 ? 1 : 0)) - oo[a]) / dd[a];
+            td = g.cell[a] / fabs(dd[a]);
         }
-    }
+    };
+    setup(0, ix, sx, mx, ex); setup(1, iy, sy, my, ey); setup(2, iz, sz, mz, ez);
     const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
     for (int it = 0; it < max_steps; ++it) {
-        const uint32_t c = (uint32_t)((idx[2] * g.n[1] + idx[1]) * g.n[0] + idx[0]);
+        const uint32_t c = (uint32_t)((iz * g.n[1] + iy) * g.n[0] + ix);
         const uint32_t k1 = g.cell_start[c + 1];
         for (uint32_t k = g.cell_start[c]; k < k1; ++k) { const int j = (int)g.items[k]; grid_candidate(surf[j], j, o, d, best, bs, bcode); }
-        const int ax = t_max[0] <= t_max[1] ? (t_max[0] <= t_max[2] ? 0 : 2) : (t_max[1] <= t_max[2] ? 1 : 2);
-        const double t_exit = t_max[ax];
+        const double t_exit = fmin(mx, fmin(my, mz));
         if (best < t_exit - 1e-9 * (1.0 + fabs(t_exit))) return;
-        idx[ax] += step[ax];
-        if (idx[ax] < 0 || idx[ax] >= g.n[ax]) return;
-        t_max[ax] += t_delta[ax];
+        if (mx <= my && mx <= mz) { ix += sx; if (ix < 0 || ix >= g.n[0]) return; mx += ex; }
+        else if (my <= mz) { iy += sy; if (iy < 0 || iy >= g.n[1]) return; my += ey; }
+        else { iz += sz; if (iz < 0 || iz >= g.n[2]) return; mz += ez; }
     }
 }
 
@@ -279,7 +278,7 @@ __device__ __forceinline__ bool primary_pixel(const TraceArgs& a, uint32_t idx, 
     return r < (uint32_t)a.fp.band_rows && px < (uint32_t)a.fp.width;
 }
 
-template <bool PRIMARY>
+template <bool PRIMARY, bool GRID>
 __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     __shared__ SurfD tile[SURF_TILE];
     __shared__ uint32_t s_cnt[3][TRACE_BLOCK / 64];
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
 
-    const bool use_grid = a.grid.cell_start != nullptr;  // lanes walk their own cells: surfaces come from global memory (L2)
+    constexpr bool use_grid = GRID;  // lanes walk their own cells: surfaces come from global memory (L2)
     const bool single_tile = S <= SURF_TILE && !use_grid;
     if (single_tile) {
         // the whole surface list is staged once per workgroup
@@ -470,7 +469,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 // serialise on the counter word).  Needs the whole surface list in one LDS tile, or the grid.
 // ---------------------------------------------------------------------------------------
 #define TAIL_BLOCK RT_TAIL_BLOCK
-template <bool PRIMARY>
+template <bool PRIMARY, bool GRID>
 __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     __shared__ SurfD tile[SURF_TILE];
     __shared__ uint32_t s_cnt[TAIL_BLOCK / 64];
@@ -479,7 +478,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     uint32_t count;
     if (PRIMARY) count = primary_slots(a);
     else { count = *a.in.count; if (count > a.in.capacity) count = a.in.capacity; }
-    const bool use_grid = a.grid.cell_start != nullptr;
+    constexpr bool use_grid = GRID;
     if (!use_grid) {
         const double* src = (const double*)a.surf;
         double* dst = (double*)tile;
@@ -608,11 +607,23 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
 }
 
 void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s) {
-    if (a.depth == 0) hipLaunchKernelGGL(k_trace_tail<true>, dim3(blocks), dim3(TAIL_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_trace_tail<false>, dim3(blocks), dim3(TAIL_BLOCK), 0, s, a);
+    const dim3 g(blocks), b(TAIL_BLOCK);
+    if (a.grid.cell_start) {
+        if (a.depth == 0) hipLaunchKernelGGL((k_trace_tail<true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_trace_tail<false, true>), g, b, 0, s, a);
+    } else {
+        if (a.depth == 0) hipLaunchKernelGGL((k_trace_tail<true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_trace_tail<false, false>), g, b, 0, s, a);
+    }
 }
 
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s) {
-    if (a.depth == 0) hipLaunchKernelGGL(k_trace<true>, dim3(blocks), dim3(TRACE_BLOCK), 0, s, a);
-    else hipLaunchKernelGGL(k_trace<false>, dim3(blocks), dim3(TRACE_BLOCK), 0, s, a);
+    const dim3 g(blocks), b(TRACE_BLOCK);
+    if (a.grid.cell_start) {
+        if (a.depth == 0) hipLaunchKernelGGL((k_trace<true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_trace<false, true>), g, b, 0, s, a);
+    } else {
+        if (a.depth == 0) hipLaunchKernelGGL((k_trace<true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_trace<false, false>), g, b, 0, s, a);
+    }
 }
