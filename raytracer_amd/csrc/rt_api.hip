@@ -89,6 +89,7 @@ struct rt_handle {
     std::vector<int32_t> rows_on_device;  // what d_row_y holds
     uint2* d_deferred = nullptr;
     int arena_lights = 0;
+    bool arena_has_rays = false;     // the arena holds full-size ray queues
     int32_t* d_row_y = nullptr;
     size_t row_y_cap = 0;
     float* d_out_f32 = nullptr;
@@ -117,20 +118,35 @@ void free_frame_buffers(rt_handle* h) {
     h->arena = nullptr;
     h->band_capacity = 0;
     h->arena_lights = 0;
+    h->arena_has_rays = false;
     h->accum_zero_prefix = 0;
 }
 
 // carve the SoA queues out of one arena
+// Depth from which one k_trace_tail launch replaces the per-level launches (>= depths: never).
+// Whenever the surface list fits one LDS tile the whole tree, camera rays included, runs in one
+// launch: no ray queue traffic, no launch per level (measured 0.45 ms against 0.92 ms on the 4K
+// pool frame, 0.55 against 0.89 ms on the 1080p transparency scene).  The choice never changes
+// the image.
+int choose_tail_depth(const rt_handle* h, int depths) {
+    if ((h->S > RT_SURF_TILE && !h->grid.cell_start) || depths < 2) return depths;
+    if (h->tail_override == 0) return depths;
+    if (h->tail_override > 0) return std::min(h->tail_override, depths);
+    return 0;
+}
+
 // camera rays are enumerated in 8 x 8 pixel tiles; each owns one shade slot (rt_trace.hip: primary_slots)
 size_t primary_slots(size_t width, size_t rows) { return ((width + 7) / 8) * ((rows + 7) / 8) * 64; }
 
 int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const int lights = h->L > 0 ? h->L : 1;
-    if (pixels <= h->band_capacity && lights <= h->arena_lights) return RT_OK;
+    // the ping-pong ray queues are only needed when some level has a launch of its own
+    const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
+    if (pixels <= h->band_capacity && lights <= h->arena_lights && (!need_rays || h->arena_has_rays)) return RT_OK;
     if (pixels < h->band_capacity) pixels = h->band_capacity;
     if (pixels < kMinArenaPixels) pixels = kMinArenaPixels;  // head-room for deep ray trees of small frames
     free_frame_buffers(h);
-    const size_t rcap = pixels * kRayFactor, scap = pixels * kShadeFactor;
+    const size_t rcap = need_rays ? pixels * kRayFactor : 64, scap = pixels * kShadeFactor;
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t bytes = 0;
     bytes += 2 * (4 * al(rcap * 16) + al(rcap * 4));     // two ray queues
@@ -160,6 +176,7 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     h->d_deferred = (uint2*)take(dcap * sizeof(uint2));
     h->band_capacity = pixels;
     h->arena_lights = lights;
+    h->arena_has_rays = need_rays;
     return RT_OK;
 }
 
@@ -181,18 +198,6 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
 }
 
 struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
-
-// Depth from which one k_trace_tail launch replaces the per-level launches (>= depths: never).
-// Whenever the surface list fits one LDS tile the whole tree, camera rays included, runs in one
-// launch: no ray queue traffic, no launch per level (measured 0.45 ms against 0.92 ms on the 4K
-// pool frame, 0.55 against 0.89 ms on the 1080p transparency scene).  The choice never changes
-// the image.
-int choose_tail_depth(const rt_handle* h, int depths) {
-    if ((h->S > RT_SURF_TILE && !h->grid.cell_start) || depths < 2) return depths;
-    if (h->tail_override == 0) return depths;
-    if (h->tail_override > 0) return std::min(h->tail_override, depths);
-    return 0;
-}
 
 int ensure_tail_stack(rt_handle* h, int blocks) {
     if (!h->both_children) return RT_OK;  // no hit can park a child: the kernel gets stack_levels = 0
