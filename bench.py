@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pool_n16_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-brute-force", action="store_true",
+                    help="skip the RT_FLAG_NO_CULL frames after the timed region (profiling runs: keeps per-kernel averages clean)")
     ap.add_argument("--no-cull", action="store_true",
                     help="brute force: every shadow ray against every surface (RT_FLAG_NO_CULL), for A/B numbers")
     args = ap.parse_args()
@@ -126,7 +128,7 @@ def main():
     # the same frame with RT_FLAG_NO_CULL (every shadow ray against every surface): what the straightforward
     # kernel reaches of the vector peak; outside the timed region, rank 0 of a single-GPU run only
     brute = None
-    if world == 1 and not args.no_cull and args.workload == "pool_n16_4k":
+    if world == 1 and not args.no_cull and not args.no_brute_force and args.workload == "pool_n16_4k":
         drb = DistributedRenderer(renderer, W, H, flags=2)
         drb.render(seed=0)
         bms = bfl = 0.0
