@@ -169,7 +169,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"scenes/{scene_name}.txt at {W}x{H} (pool geometry, 16x16 soft-shadow grid, "
-                                   "max_recursions 10; BASELINE configs[4])" if args.workload == "pool_n16_4k"
+                                   "max_recursions 10)" if args.workload == "pool_n16_4k"
                        else f"scenes/{scene_name}.txt at {W}x{H}",
                        "rays_per_frame": rays_total / steps, "partition": f"row stripes x{world}, uint8 gather to rank 0",
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},

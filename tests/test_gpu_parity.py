@@ -63,7 +63,7 @@ def test_frames_match_reference_goldens(renderer, name, w, h):
 @pytest.mark.parametrize("key", ["cubes_1920x1080", "transparency_v7_1920x1080", "pool_3840x2160", "pool_n16_3840x2160",
                                  "synthetic_10k_1k_3840x2160"])
 def test_benchmark_configs_at_full_size_against_reference_pixels(renderer, key):
-    """The BASELINE configs at their real resolution: the reference's colours at sparse pixels."""
+    """The benchmark configurations at their real resolution: the reference's colours at sparse pixels."""
     z = golden_npz(f"sparse/{key}.npz")
     name = key.rsplit("_", 1)[0]
     w, h = int(z["width"]), int(z["height"])
