@@ -114,14 +114,14 @@ def main():
         dr.render(seed=i)
     barrier()
     t0 = time.perf_counter()
-    rays = 0
-    wave_light = [0] * 8
-    ms_shade = flop_shade = ms_trace = ms_resolve = 0.0
+    # the K frames are queued back to back (render, gather, assembly: no host round trip between frames) and
+    # collected once; every kernel still carries its own HIP events, read when the frames are collected
     for i in range(args.steps):
-        _, st = dr.render(seed=1000 + i)
-        rays += st["total_rays"]
-        wave_light = [x + y for x, y in zip(wave_light, st["wave_light"])]
-        ms_shade += st["ms_shade"]; flop_shade += st["flop_shade"]; ms_trace += st["ms_trace"]; ms_resolve += st["ms_resolve"]
+        dr.enqueue(seed=1000 + i)
+    st = dr.finish()
+    rays = st["total_rays"]
+    wave_light = list(st["wave_light"])
+    ms_shade, flop_shade, ms_trace, ms_resolve = st["ms_shade"], st["flop_shade"], st["ms_trace"], st["ms_resolve"]
     barrier()
     dt = time.perf_counter() - t0
 

@@ -158,6 +158,21 @@ int rt_render(rt_handle* h, const rt_render_params* p, float* host_rgb_f32, uint
 int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
                      void* stream, rt_stats* stats);
 
+/* Frame loops that must not stall on the host between frames (serving, the multi-GPU
+ * gather): rt_render_enqueue puts one frame on `stream` like rt_render_device and returns
+ * at once; rt_render_wait blocks until every enqueued frame is done, reports whether one
+ * of them outgrew the ray / shade queues (RT_ERR_QUEUE: that frame's output is invalid and
+ * has to be rendered again with rt_render_device, which resizes) and returns the SUMS of
+ * the frames' statistics.  The selection must fit one row band (at most 3840x2160 pixels);
+ * all frames between two waits must use the same stream; the outputs of frame k may be
+ * consumed by later work on that stream without waiting.  Up to 8 frames are kept in
+ * flight (the 9th enqueue waits for the oldest).  Every other call on the handle first
+ * waits for the enqueued frames.  No counterpart in the reference (its render() is
+ * synchronous by nature).                                                           */
+int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
+                      void* stream);
+int rt_render_wait(rt_handle* h, rt_stats* stats);
+
 /* Number of rows selected by p (size of the output in rows).                       */
 int rt_rows_selected(const rt_render_params* p);
 

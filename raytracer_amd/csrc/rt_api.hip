@@ -40,6 +40,7 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
+constexpr int kAsyncDepth = 8;         // frames rt_render_enqueue keeps in flight
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
 constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
@@ -97,6 +98,13 @@ struct rt_handle {
     size_t out_cap = 0;              // values
     void* arena = nullptr;           // one allocation behind all queue arrays
     hipEvent_t ev[5]{};
+    // frames enqueued by rt_render_enqueue and not yet collected
+    struct Pending { hipEvent_t ev[4]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
+    Pending ring[kAsyncDepth];
+    bool ring_ready = false;
+    int ring_head = 0, ring_count = 0;   // oldest entry, entries in flight
+    rt_stats async_sum{};                // statistics of collected frames since the last rt_render_wait
+    bool async_overflow = false;
 };
 
 namespace {
@@ -218,8 +226,12 @@ int ensure_tail_stack(rt_handle* h, int blocks) {
 }
 
 // enqueue one band; rows[r0..r1) ; outputs are device pointers to the band's first value (may be null)
+// With `ev` / `host_counters` given (a ring entry: events of its own, pinned counters) the band is only
+// enqueued; otherwise the handle's events are used and the call returns after the stream has drained.
 int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n_rows, float* d_f32, uint8_t* d_u8,
-             hipStream_t st, bool debug, BandResult* res) {
+             hipStream_t st, bool debug, BandResult* res, hipEvent_t* ev = nullptr, unsigned long long* host_counters = nullptr) {
+    const bool enqueue_only = ev != nullptr;
+    if (!ev) ev = h->ev;
     const size_t pixels = (size_t)n_rows * p->width;
     const size_t slots0 = primary_slots((size_t)p->width, (size_t)n_rows);
     // thin bands pad their tiles up to 8 rows: make room for the camera rays' slots plus as many appended hits
@@ -229,9 +241,10 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     }
     h->sq.base = (uint32_t)slots0;
     if (h->rows_on_device.size() != (size_t)n_rows || std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) {
-        h->rows_on_device.clear();  // stays empty if the copy fails
-        HIP_TRY(h, hipMemcpyAsync(h->d_row_y, rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
-        h->rows_on_device.assign(rows, rows + n_rows);
+        h->rows_on_device.assign(rows, rows + n_rows);  // the copy reads this vector, which outlives the call
+        hipError_t e = hipMemcpyAsync(h->d_row_y, h->rows_on_device.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) h->rows_on_device.clear();
+        HIP_TRY(h, e);
     }
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts, st));
     if (h->accum_zero_prefix < 3 * pixels) {
@@ -247,7 +260,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     fp.bg[0] = h->bg[0]; fp.bg[1] = h->bg[1]; fp.bg[2] = h->bg[2];
     fp.row_y = h->d_row_y;
 
-    HIP_TRY(h, hipEventRecord(h->ev[0], st));
+    HIP_TRY(h, hipEventRecord(ev[0], st));
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
     const int tail_from = choose_tail_depth(h, depths);
@@ -271,7 +284,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         if (d == 0) blocks = (int)std::min<size_t>((slots0 + RT_TRACE_BLOCK - 1) / RT_TRACE_BLOCK, (size_t)max_blocks);
         rt_launch_trace(ta, std::max(blocks, 1), st);
     }
-    HIP_TRY(h, hipEventRecord(h->ev[1], st));
+    HIP_TRY(h, hipEventRecord(ev[1], st));
     if (!debug) {
         ShadeArgs sa{};
         sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq; sa.grid = h->grid;
@@ -287,20 +300,61 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
-    HIP_TRY(h, hipEventRecord(h->ev[2], st));
+    HIP_TRY(h, hipEventRecord(ev[2], st));
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels, d_f32, d_u8, st);
-    HIP_TRY(h, hipEventRecord(h->ev[3], st));
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipEventRecord(ev[3], st));  // after the counters have landed: waiting for it is enough
+    if (enqueue_only) {
+        if (!debug && (d_f32 || d_u8)) h->accum_zero_prefix = zero_before;  // stream order: later bands run after this resolve
+        return RT_OK;
+    }
     HIP_TRY(h, hipStreamSynchronize(st));
-    HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, h->ev[0], h->ev[1]));
-    HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, h->ev[1], h->ev[2]));
-    HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, h->ev[2], h->ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, ev[0], ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, ev[1], ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, ev[2], ev[3]));
     if (!debug && (d_f32 || d_u8)) h->accum_zero_prefix = zero_before;
     return RT_OK;
 }
 
+void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, float ms_trace, float ms_shade, float ms_resolve, size_t rows) {
+    s.primary_rays += c[CNT_PRIMARY]; s.secondary_rays += c[CNT_SECONDARY];
+    s.depth_cut += c[CNT_DEPTH_CUT]; s.shaded_points += c[CNT_SHADED];
+    s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_resolve += ms_resolve;
+    for (int k = 0; k < 7; ++k) s.wave_light[k] += c[CNT_WL_NONE + k];
+    s.bands += 1;
+    s.rows_rendered += rows;
+    s.shadow_rays += (uint64_t)std::llround((double)c[CNT_SHADED] * h->shadow_rays_per_hit);
+    s.flop_shade += (double)c[CNT_SHADED] * h->flop_per_hit;
+}
+
+// wait for the oldest enqueued frame and add its statistics to h->async_sum
+int collect_oldest(rt_handle* h) {
+    rt_handle::Pending& e = h->ring[h->ring_head];
+    h->ring_head = (h->ring_head + 1) % kAsyncDepth;
+    h->ring_count -= 1;
+    HIP_TRY(h, hipEventSynchronize(e.ev[3]));
+    float t0 = 0, t1 = 0, t2 = 0, all = 0;
+    HIP_TRY(h, hipEventElapsedTime(&t0, e.ev[0], e.ev[1]));
+    HIP_TRY(h, hipEventElapsedTime(&t1, e.ev[1], e.ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
+    HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
+    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE]) h->async_overflow = true;
+    add_band_stats(h, h->async_sum, e.counters, t0, t1, t2, e.rows);
+    h->async_sum.ms_total += all;
+    return RT_OK;
+}
+
+int drain(rt_handle* h) {
+    while (h->ring_count > 0) {
+        int rc = collect_oldest(h);
+        if (rc != RT_OK) { h->ring_count = 0; return rc; }
+    }
+    return RT_OK;
+}
+
 int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* d_u8, hipStream_t st, rt_stats* stats) {
+    { int rc0 = drain(h); if (rc0 != RT_OK) return rc0; }
     std::vector<int32_t> rows;
     selected_rows(p, rows);
     rt_stats s{};
@@ -342,11 +396,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
         }
-        s.primary_rays += br.c[CNT_PRIMARY]; s.secondary_rays += br.c[CNT_SECONDARY];
-        s.depth_cut += br.c[CNT_DEPTH_CUT]; s.shaded_points += br.c[CNT_SHADED];
-        s.ms_trace += br.ms_trace; s.ms_shade += br.ms_shade; s.ms_resolve += br.ms_resolve;
-        for (int k = 0; k < 7; ++k) s.wave_light[k] += br.c[CNT_WL_NONE + k];
-        s.bands += 1;
+        add_band_stats(h, s, br.c, br.ms_trace, br.ms_shade, br.ms_resolve, 0);
         r0 += n;
     }
     HIP_TRY(h, hipEventRecord(e_end, st));
@@ -355,8 +405,6 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     HIP_TRY(h, hipEventElapsedTime(&ms, e_begin, e_end));
     (void)hipEventDestroy(e_end);
     s.ms_total = ms;
-    s.shadow_rays = (uint64_t)std::llround((double)s.shaded_points * h->shadow_rays_per_hit);
-    s.flop_shade = (double)s.shaded_points * h->flop_per_hit;
     if (stats) *stats = s;
     return RT_OK;
 }
@@ -473,6 +521,11 @@ int rt_create(int device, rt_handle** out) {
 void rt_destroy(rt_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    (void)drain(h);
+    for (auto& e : h->ring) {
+        for (auto& v : e.ev) if (v) (void)hipEventDestroy(v);
+        if (e.counters) (void)hipHostFree(e.counters);
+    }
     free_frame_buffers(h);
     for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_counters,
                     (void*)h->stack_mem, (void*)h->d_grid_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
@@ -487,6 +540,7 @@ const char* rt_last_error(const rt_handle* h) { return h ? h->err.c_str() : "nul
 
 int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     if (!h) return RT_ERR_INVALID;
+    { int rc0 = drain(h); if (rc0 != RT_OK) return rc0; }
     if (!d || d->struct_size != sizeof(rt_scene_desc) || d->abi_version != RT_ABI_VERSION)
         return fail(h, RT_ERR_INVALID, "rt_scene_desc: bad struct_size / abi_version");
     if (d->n_surfaces < 0 || d->n_materials < 0 || d->n_lights < 0) return fail(h, RT_ERR_INVALID, "negative count");
@@ -613,6 +667,64 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     return RT_OK;
 }
 
+int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8, void* stream) {
+    if (!h) return RT_ERR_INVALID;
+    if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render_enqueue before rt_set_scene");
+    int rc = validate_params(h, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    std::vector<int32_t> rows;
+    selected_rows(p, rows);
+    if (rows.empty()) return RT_OK;
+    const size_t pixels = rows.size() * (size_t)p->width;
+    if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_enqueue: the selection needs more than one row band");
+    if (!h->ring_ready) {
+        for (auto& e : h->ring) {
+            for (auto& v : e.ev) HIP_TRY(h, hipEventCreate(&v));
+            HIP_TRY(h, hipHostMalloc((void**)&e.counters, sizeof(unsigned long long) * CNT_N));
+        }
+        h->ring_ready = true;
+    }
+    // anything that reallocates device memory waits for the frames in flight first
+    const size_t need_px = std::max(pixels, (primary_slots((size_t)p->width, rows.size()) * 2 + kShadeFactor - 1) / kShadeFactor);
+    const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
+    if (rows.size() > h->row_y_cap || need_px > h->band_capacity || (h->L > 0 ? h->L : 1) > h->arena_lights ||
+        (need_rays && !h->arena_has_rays)) {
+        rc = drain(h);
+        if (rc != RT_OK) return rc;
+        if (rows.size() > h->row_y_cap) {
+            if (h->d_row_y) (void)hipFree(h->d_row_y);
+            h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
+            HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
+            h->row_y_cap = rows.size();
+        }
+    }
+    if (h->ring_count == kAsyncDepth) { rc = collect_oldest(h); if (rc != RT_OK) return rc; }
+    rc = ensure_band_capacity(h, need_px);  // no-op unless drained above (or the first frame)
+    if (rc != RT_OK) return rc;
+    rt_handle::Pending& e = h->ring[(h->ring_head + h->ring_count) % kAsyncDepth];
+    e.rows = rows.size();
+    BandResult br{};
+    rc = run_band(h, p, rows.data(), (int)rows.size(), (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, false, &br, e.ev, e.counters);
+    if (rc != RT_OK) return rc;
+    h->ring_count += 1;
+    return RT_OK;
+}
+
+int rt_render_wait(rt_handle* h, rt_stats* stats) {
+    if (!h) return RT_ERR_INVALID;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = drain(h);
+    if (stats) *stats = h->async_sum;
+    const bool overflow = h->async_overflow;
+    h->async_sum = rt_stats{};
+    h->async_overflow = false;
+    if (rc != RT_OK) return rc;
+    if (overflow) return fail(h, RT_ERR_QUEUE, "an enqueued frame outgrew the ray / shade queues: render it again with rt_render_device");
+    return RT_OK;
+}
+
 int rt_rows_selected(const rt_render_params* p) {
     if (!p || p->stripe_rows < 1 || p->stripe_count < 1) return RT_ERR_INVALID;
     int n = 0;
@@ -667,6 +779,7 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
     if (rows.empty()) return RT_OK;
     const size_t pixels = rows.size() * (size_t)p->width;
     if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "debug probe is limited to one band");
+    { int rc0 = drain(h); if (rc0 != RT_OK) return rc0; }
     if (rows.size() > h->row_y_cap) {
         if (h->d_row_y) (void)hipFree(h->d_row_y);
         h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();

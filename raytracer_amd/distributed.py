@@ -118,3 +118,16 @@ class DistributedRenderer(TileGatherer):
                                           stripe_rows=self.stripe_rows, stripe_count=self.world, stripe_index=self.rank,
                                           flags=self.flags)
         return self.gather(), stats
+
+    def enqueue(self, seed=0):
+        """Put one frame (render + gather + assembly) on the stream without waiting for it; returns the frame
+        tensor on rank 0 (valid for later work on the same stream).  ``finish()`` collects the statistics."""
+        stream = self.torch.cuda.current_stream(self.tile.device).cuda_stream
+        self.r.enqueue_rows_device(self.W, self.H, 0, self.tile.data_ptr(), stream=stream, seed=seed,
+                                   stripe_rows=self.stripe_rows, stripe_count=self.world, stripe_index=self.rank,
+                                   flags=self.flags)
+        return self.gather()
+
+    def finish(self):
+        """Wait for every enqueued frame of this rank; returns the summed stats dict."""
+        return self.r.wait()

@@ -17,7 +17,7 @@ from . import packing
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_amd.so")
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_render", "rt_render_device",
-           "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
+           "rt_render_enqueue", "rt_render_wait", "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
 
 HF_CBATCH_POS, HF_CDOT_POS, HF_BOX_OUTSIDE, HF_NO_OWN = 1, 2, 4, 8
 
@@ -53,6 +53,10 @@ def load_library():
     L.rt_render.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, C.POINTER(packing.RtStats)]
     L.rt_render_device.restype = C.c_int
     L.rt_render_device.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp, C.POINTER(packing.RtStats)]
+    L.rt_render_enqueue.restype = C.c_int
+    L.rt_render_enqueue.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp]
+    L.rt_render_wait.restype = C.c_int
+    L.rt_render_wait.argtypes = [vp, C.POINTER(packing.RtStats)]
     L.rt_rows_selected.restype = C.c_int
     L.rt_rows_selected.argtypes = [C.POINTER(packing.RtRenderParams)]
     L.rt_debug_hits.restype = C.c_int
@@ -132,6 +136,18 @@ class Renderer:
         st = packing.RtStats()
         self._check(self._lib.rt_render_device(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None,
                                                stream or None, C.byref(st)))
+        return _stats_dict(st)
+
+    def enqueue_rows_device(self, width, height, dev_f32_ptr, dev_u8_ptr, *, stream=None, seed=0, row_begin=0,
+                            row_end=None, stripe_rows=1, stripe_count=1, stripe_index=0, flags=0):
+        """Like ``render_rows_device`` but returns as soon as the frame is on the stream; ``wait()`` collects."""
+        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed, flags)
+        self._check(self._lib.rt_render_enqueue(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None, stream or None))
+
+    def wait(self):
+        """Block until every enqueued frame is done; returns the summed stats dict (raises if one overflowed)."""
+        st = packing.RtStats()
+        self._check(self._lib.rt_render_wait(self._h, C.byref(st)))
         return _stats_dict(st)
 
     def render(self, scene, width, height, *, seed=0):

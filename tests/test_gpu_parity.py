@@ -384,3 +384,32 @@ def test_grid_forced_on_small_scenes(oracle, monkeypatch, name):
             assert (st.primary_rays, st.secondary_rays, st.shaded_points) == (cnt["primary"], cnt["secondary"], cnt["shaded"])
     finally:
         r.close()
+
+
+def test_enqueued_frames_equal_synchronous_frames(renderer):
+    """rt_render_enqueue / rt_render_wait: frames queued back to back (more than the 8 kept in flight) give the
+    images and, summed, the statistics of the same frames rendered one call at a time."""
+    import torch
+    w, h = 160, 90
+    renderer.set_scene(scene("transparency_v7"))
+    seeds = list(range(11))
+    want, total = [], None
+    for s in seeds:
+        _, u8, st = renderer.render_rows(w, h, seed=s, want_f32=False)
+        want.append(u8)
+        keys = ("primary_rays", "secondary_rays", "depth_cut", "shaded_points", "shadow_rays", "rows_rendered", "bands")
+        total = {k: (total[k] if total else 0) + st[k] for k in keys}
+    bufs = [torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda") for _ in seeds]
+    stream = torch.cuda.current_stream().cuda_stream
+    for s, b in zip(seeds, bufs):
+        renderer.enqueue_rows_device(w, h, 0, b.data_ptr(), stream=stream, seed=s)
+    st = renderer.wait()
+    for b, u8 in zip(bufs, want):
+        m = CI.metrics(u8, b.cpu().numpy())
+        assert m["max_abs_diff"] <= 1 and m["within_1lsb"] == 1.0     # float64 atomics: order effects stay below 1 LSB
+    assert {k: st[k] for k in total} == total
+    assert st["ms_shade"] > 0 and st["ms_trace"] > 0
+    assert renderer.wait()["primary_rays"] == 0                       # nothing left in flight
+    # a frame that needs several row bands is refused, the synchronous call handles it
+    with pytest.raises(runtime.RtError):
+        renderer.enqueue_rows_device(3840, 2161, 0, bufs[0].data_ptr(), stream=stream)
