@@ -219,9 +219,12 @@ __device__ __forceinline__ HitFrame hit_frame(const SurfD& sf, d3 o, d3 d, doubl
     return f;
 }
 
-__device__ __forceinline__ void store_shade(const ShadeQueue& q, uint32_t slot, d3 o, const HitFrame& f, float tr, float tg, float tb,
+__device__ __forceinline__ void store_shade(const ShadeQueue& q, uint32_t slot, d3 d, const HitFrame& f, float tr, float tg, float tb,
                                             float transp, uint32_t lpix, uint32_t gpix, uint32_t node, int bs) {
-    d3 view = normalize(sub(o, f.P));           // ray_tracer.py:275
+    // view = normalize(origin - hit) (ray_tracer.py:275) = -d up to a few float64 ulps, because every ray direction
+    // is unit length by construction (normalised camera ray, reflection of a unit vector, unchanged direction);
+    // it is only consumed in FP32, where the two agree, so the float64 sqrt and three divides are not spent on it
+    d3 view = D3(-d.x, -d.y, -d.z);
     float om = (float)(1.0 - (double)transp);   // material.py:28
     q.r0[slot] = make_float4((float)f.P.x, (float)f.P.y, (float)f.P.z, (float)f.n.x);
     q.r1[slot] = make_float4((float)f.n.y, (float)f.n.z, (float)view.x, (float)view.y);
@@ -396,12 +399,12 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         // ---- shading record -----------------------------------------------------------
         if (PRIMARY) {
             if (idx < count) {  // every slot of the camera rays is written: a record or the null mark
-                if (hit) { store_shade(a.shade, idx, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
+                if (hit) { store_shade(a.shade, idx, d, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
                 else a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
             }
         } else if (push_s) {
             if (slot_s < a.shade.capacity) {
-                store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
+                store_shade(a.shade, slot_s, d, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
                 n_shaded += 1;
             } else ovf_shade += 1;
         }
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             if (have && !hit) add_background(a, lpix, tr, tg, tb);
             const bool push_s = hit && !first;
             if (first && have) {
-                if (hit) { store_shade(a.shade, idx, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
+                if (hit) { store_shade(a.shade, idx, d, f, tr, tg, tb, m.transp, lpix, gpix, node, bs); n_shaded += 1; }
                 else a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
             }
             first = false;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             const uint32_t slot_s = a.shade.base + s_base + s_cnt[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
             if (push_s) {
                 if (slot_s < a.shade.capacity) {
-                    store_shade(a.shade, slot_s, o, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
+                    store_shade(a.shade, slot_s, d, f, tr, tg, tb, m.transp, lpix, gpix, node, bs);
                     n_shaded += 1;
                 } else ovf_shade += 1;
             }
