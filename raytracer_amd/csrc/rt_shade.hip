@@ -50,14 +50,22 @@ __device__ __forceinline__ f3 normalize(f3 v) {
 __device__ __forceinline__ float pow_pos(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 __device__ __forceinline__ float comp(f3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
+// Quarter discriminant of the unit-direction quadratic, b^2 - c with c = |oc|^2 - r^2, evaluated as
+// r^2 - |oc - b w|^2 (squared distance of the centre from the ray): the literal form cancels two numbers
+// of size |oc|^2 and is noise in FP32 once the hit point is a few hundred radii away (a ground plane seen
+// near the horizon), this one stays accurate to ~1e-7 |oc| in the distance.
+__device__ __forceinline__ float sphere_disc(f3 oc, f3 w, float b, float r2) {
+    const f3 q = F3(fmaf(-b, w.x, oc.x), fmaf(-b, w.y, oc.y), fmaf(-b, w.z, oc.z));
+    return r2 - dot(q, q);
+}
+
 // ---------------------------------------------------------------------------------------
 // multi-sample path: semantics of intersect_batch + mask (ray_tracer.py:70-73)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ bool sphere_blocks_b(const SurfF& s, f3 P, f3 w, float dist, bool own, uint32_t flags) {
     f3 oc = P - F3(s.a.x, s.a.y, s.a.z);
     float b = dot(w, oc);                    // half of the reference's b (unit direction, a = 1)
-    float c = dot(oc, oc) - s.a.w;
-    float disc = fmaf(b, b, -c);
+    float disc = sphere_disc(oc, w, b, s.a.w);
     float sq = __fsqrt_rn(fmaxf(disc, 0.f));
     float t1 = -b - sq, t2 = -b + sq;
     float tn = t1 > 0.f ? t1 : t2;           // sphere.py:119
@@ -105,8 +113,7 @@ __device__ __forceinline__ bool box_blocks_b(const SurfF& s, f3 P, f3 w, float d
 __device__ __forceinline__ bool sphere_blocks_a(const SurfF& s, f3 P, f3 w, float dist, bool own, uint32_t flags) {
     f3 oc = P - F3(s.a.x, s.a.y, s.a.z);
     float b = dot(w, oc);
-    float c = dot(oc, oc) - s.a.w;
-    float disc = fmaf(b, b, -c);
+    float disc = sphere_disc(oc, w, b, s.a.w);
     if (own) {
         float t = -2.f * b;
         return b < 0.f && !(flags & HF_CDOT_POS) && t > RT_EPSF && t < dist;
@@ -623,6 +630,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
         const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);  // own sphere: oc
         const bool own_sph_blocks = own_sphere && !(h.flags & HF_CBATCH_POS);
 
+        const float pfuzz_hit = 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z));
+
         f3 color = F3(0.f, 0.f, 0.f);
         for (int l = l_first; l < L; l += (int)G) {
             const LightF lt = a.light[l];
@@ -638,7 +647,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 const f3 right = normalize(cross(ldir, perp));
                 const f3 up = normalize(cross(right, ldir));
                 const float llen = lc2 * linv;
-                const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f;
+                // radius of the sample square's circumcircle, plus the rounding allowance of the reach tests: positions
+                // carry ~1e-7 of their magnitude, which matters for hit points far away (a ground plane near the horizon)
+                const float rho_base = lt.radius * 0.70710678f * 1.0002f + 1e-6f;
+                const float rho = rho_base + fmaf(4e-7f, llen, pfuzz_hit);
                 const float inv_lc2 = linv * linv;
                 const float s_hi_scale = llen > 1.5f * rho ? 1.0002f / (llen - rho) : 1e30f;
                 // a light whose Phong terms vanish for this hit (back-facing and no specular lobe
@@ -670,7 +682,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                             if (!never) {
                                 reach_bits |= 1u << j;
                                 const float lmin = llen - rho;
-                                const bool linear_ok = c >= 1e-3f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
+                                // (beyond ~100 radii the cone's opening is below what an FP32 cosine resolves)
+                                const bool linear_ok = c >= 1e-3f * r * r && c < 1e4f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
                                 if (!linear_ok) gen = true;
                                 else {
                                     const float k = -__builtin_amdgcn_rsqf(c);
@@ -687,7 +700,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                             const bool never = own || !lit || (ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0));
                             if (!never) {
                                 reach_bits |= 1u << j;
-                                if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho))) gen = true;
+                                if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho) && ah > 64.f * (rho - rho_base))) gen = true;
                                 else {
                                     A[j] = (dn0 - ah) * PLANE_SCALE; B[j] = dot(right, n) * (sg * PLANE_SCALE); C[j] = dot(up, n) * (sg * PLANE_SCALE);
                                     lin |= 1u << j;
@@ -913,7 +926,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             ratio = f;
         } else {
             // ---- per-(hit, surface) constants
-            float g[SMALL_MAX][HAS_BOX ? 6 : 4];
+            float g[SMALL_MAX][HAS_BOX ? 6 : 5];
 #pragma unroll
             for (int j = 0; j < SMALL_MAX; ++j) {
 #pragma unroll
@@ -925,6 +938,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                         const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
                         g[j][0] = oc.x; g[j][1] = oc.y; g[j][2] = oc.z;
                         g[j][3] = own ? -INFINITY : 0.f - (dot(oc, oc) - sf.a.w);
+                        g[j][4] = own ? -1.f : sf.a.w;  // r^2; own sphere: never a root here (resolved by rule below)
                     } else if (STYPE(j) == RT_SURF_PLANE) {
                         g[j][0] = sf.a.x; g[j][1] = sf.a.y; g[j][2] = sf.a.z;
                         g[j][3] = own ? NAN : sf.a.w - dot(P, F3(sf.a.x, sf.a.y, sf.a.z));
@@ -986,7 +1000,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                             bool blk;
                             if (STYPE(s) == RT_SURF_SPHERE) {
                                 const float b = fmaf(w.z, g[s][2], fmaf(w.y, g[s][1], w.x * g[s][0]));
-                                const float disc = fmaf(b, b, g[s][3]);
+                                const float disc = sphere_disc(F3(g[s][0], g[s][1], g[s][2]), w, b, g[s][4]);
                                 const float sq = __builtin_amdgcn_sqrtf(disc);  // NaN when the ray misses
                                 const float ssq = copysignf(sq, g[s][3]);       // outside: near root, inside: far root
                                 const float tn = ssq - b;

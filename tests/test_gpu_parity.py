@@ -413,3 +413,76 @@ def test_enqueued_frames_equal_synchronous_frames(renderer):
     # a frame that needs several row bands is refused, the synchronous call handles it
     with pytest.raises(runtime.RtError):
         renderer.enqueue_rows_device(3840, 2161, 0, bufs[0].data_ptr(), stream=stream)
+
+
+def _random_scene_text(seed):
+    """Small random scenes: 3..14 surfaces of all three kinds (some touching or overlapping), reflective and
+    transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5."""
+    rng = np.random.default_rng(seed)
+
+    def q(lo, hi):
+        return round(float(rng.uniform(lo, hi)) * 256.0) / 256.0
+
+    n_mat = int(rng.integers(2, 6))
+    lines = [f"cam {q(-1, 1)!r} {q(1, 3)!r} {q(5, 8)!r}  {q(-0.5, 0.5)!r} {q(0, 1)!r} 0  0 1 0  {q(1, 1.6)!r} {q(1.2, 2)!r}",
+             f"set {q(0, 1)!r} {q(0, 1)!r} {q(0, 1)!r} {int(rng.integers(1, 5))} {int(rng.integers(1, 6))}"]
+    for _ in range(n_mat):
+        refl = q(0.1, 0.6) if rng.random() < 0.4 else 0.0
+        transp = q(0.2, 0.8) if rng.random() < 0.35 else 0.0
+        shin = [0.0, 1.0, 8.0, 30.0, 100.0][int(rng.integers(0, 5))]
+        lines.append(f"mtl {q(0.1, 1)!r} {q(0.1, 1)!r} {q(0.1, 1)!r}  {q(0, 1)!r} {q(0, 1)!r} {q(0, 1)!r}  "
+                     f"{refl!r} {refl!r} {refl!r}  {shin!r} {transp!r}")
+    lines.append(f"pln 0 1 0 {q(-1, 0)!r} {int(rng.integers(1, n_mat + 1))}")
+    if rng.random() < 0.5:
+        lines.append(f"pln {q(-0.3, 0.3)!r} {q(-0.2, 0.2)!r} 1 {q(-8, -4)!r} {int(rng.integers(1, n_mat + 1))}")
+    for _ in range(int(rng.integers(2, 13))):
+        m = int(rng.integers(1, n_mat + 1))
+        if rng.random() < 0.6:
+            lines.append(f"sph {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.2, 1.0)!r} {m}")
+        else:
+            lines.append(f"box {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.3, 1.4)!r} {m}")
+    for _ in range(int(rng.integers(1, 4))):
+        shadow = 0.0 if rng.random() < 0.2 else q(0.3, 1)
+        lines.append(f"lgt {q(-4, 4)!r} {q(2, 6)!r} {q(-2, 5)!r}  {q(0.3, 1)!r} {q(0.3, 1)!r} {q(0.3, 1)!r}  {q(0, 1)!r} {shadow!r} {q(0.2, 2.5)!r}")
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_scenes_match_the_oracle(renderer, oracle, tmp_path, seed):
+    """Geometry chain bit for bit, counters exactly, image within 1 LSB -- on scenes nobody tuned the kernels for."""
+    sc = R.parse_scene_file(write_scene(tmp_path, _random_scene_text(1000 + seed)))
+    w, h = 72, 48
+    renderer.set_scene(sc)
+    _, u8, st = renderer.render_rows(w, h, seed=seed)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=seed, threads=THREADS)
+    assert counters_of(st) == cnt
+    m = CI.metrics(np.uint8(ref), u8)
+    assert m["pixels_beyond_1lsb"] <= 3, m            # 3456 pixels: 99.9 %
+    xs, ys = grid(w, h)
+    _, _, oh = oracle.render_pixels(sc, w, h, xs, ys, seed=seed, record_hits=True)
+    hb = renderer.debug_hits(w, h, capacity=len(oh) + 64)
+    assert hb["count"] == len(oh)
+    want = {(o[0], o[1]): o for o in oh}
+    for i in range(hb["count"]):
+        o = want[(int(hb["pixel"][i]), int(hb["node"][i]))]
+        assert (o[2], o[3]) == (hb["surf"][i], hb["t"][i])
+        assert o[4] == tuple(hb["P"][i]) and o[5] == tuple(hb["n"][i])
+
+
+def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
+    """Hit points tens of thousands of units away (a level camera over an infinite plane): their shadow rays
+    graze the objects near the origin from afar, where the literal FP32 sphere quadratic is pure cancellation."""
+    text = ("cam 0 1.7 6  0.4 1.7172 0  0 1 0  1.6 1.5\nset 0.6 0.7 0.9 2 3\n"
+            "mtl 0.6 0.5 0.7  0.8 0.7 0.8  0.2 0.2 0.2  30 0.5\nmtl 0.5 0.7 0.4  0.8 0.1 0.9  0.5 0.5 0.5  0 0\n"
+            "pln 0 1 0 -0.25 2\nsph 1.2 1.4 -2.8 0.65 1\nsph 1.7 0.75 1.7 0.28 2\nbox -1.9 -0.4 -1.6 0.35 1\n"
+            "sph -1.25 1.3 -2.3 0.66 1\nbox -0.35 1.8 -1.3 0.5 2\n"
+            "lgt -1.8 4.2 0.75  0.8 0.5 0.35  0.5 0.5 0.9\nlgt -0.8 5.3 4.2  0.5 0.8 0.4  0.65 0.7 1.5\n")
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    w, h = 160, 96
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=0, threads=THREADS)
+    _, _, oh = oracle.render_pixels(sc, w, h, *grid(w, h), seed=0, record_hits=True)
+    assert sum(o[2] == 0 and o[3] > 1e4 for o in oh) > 50    # a row of the plane is hit 30 000 units away
+    for flags in (0, 1):
+        p_u8 = renderer.render_rows(w, h, seed=0, flags=flags)[1]
+        assert_parity(p_u8, ref)
