@@ -415,17 +415,19 @@ def test_enqueued_frames_equal_synchronous_frames(renderer):
         renderer.enqueue_rows_device(3840, 2161, 0, bufs[0].data_ptr(), stream=stream)
 
 
-def _random_scene_text(seed):
+def _random_scene_text(seed, family=0):
     """Small random scenes: 3..14 surfaces of all three kinds (some touching or overlapping), reflective and
-    transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5."""
+    transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5.
+    family 1: mostly boxes, N in 4..8, wider lights."""
     rng = np.random.default_rng(seed)
+    p_sphere, n_lo, n_hi, r_hi = (0.6, 1, 5, 2.5) if family == 0 else (0.25, 4, 9, 4.0)
 
     def q(lo, hi):
         return round(float(rng.uniform(lo, hi)) * 256.0) / 256.0
 
     n_mat = int(rng.integers(2, 6))
     lines = [f"cam {q(-1, 1)!r} {q(1, 3)!r} {q(5, 8)!r}  {q(-0.5, 0.5)!r} {q(0, 1)!r} 0  0 1 0  {q(1, 1.6)!r} {q(1.2, 2)!r}",
-             f"set {q(0, 1)!r} {q(0, 1)!r} {q(0, 1)!r} {int(rng.integers(1, 5))} {int(rng.integers(1, 6))}"]
+             f"set {q(0, 1)!r} {q(0, 1)!r} {q(0, 1)!r} {int(rng.integers(n_lo, n_hi))} {int(rng.integers(1, 6))}"]
     for _ in range(n_mat):
         refl = q(0.1, 0.6) if rng.random() < 0.4 else 0.0
         transp = q(0.2, 0.8) if rng.random() < 0.35 else 0.0
@@ -437,13 +439,13 @@ def _random_scene_text(seed):
         lines.append(f"pln {q(-0.3, 0.3)!r} {q(-0.2, 0.2)!r} 1 {q(-8, -4)!r} {int(rng.integers(1, n_mat + 1))}")
     for _ in range(int(rng.integers(2, 13))):
         m = int(rng.integers(1, n_mat + 1))
-        if rng.random() < 0.6:
+        if rng.random() < p_sphere:
             lines.append(f"sph {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.2, 1.0)!r} {m}")
         else:
             lines.append(f"box {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.3, 1.4)!r} {m}")
     for _ in range(int(rng.integers(1, 4))):
         shadow = 0.0 if rng.random() < 0.2 else q(0.3, 1)
-        lines.append(f"lgt {q(-4, 4)!r} {q(2, 6)!r} {q(-2, 5)!r}  {q(0.3, 1)!r} {q(0.3, 1)!r} {q(0.3, 1)!r}  {q(0, 1)!r} {shadow!r} {q(0.2, 2.5)!r}")
+        lines.append(f"lgt {q(-4, 4)!r} {q(2, 6)!r} {q(-2, 5)!r}  {q(0.3, 1)!r} {q(0.3, 1)!r} {q(0.3, 1)!r}  {q(0, 1)!r} {shadow!r} {q(0.2, r_hi)!r}")
     return "\n".join(lines) + "\n"
 
 

@@ -10,8 +10,9 @@ from oracle import rt_oracle as O
 from test_gpu_parity import _random_scene_text
 
 r = runtime.Renderer(0)
+family = int(os.environ.get('FAMILY', '0'))
 for seed in [int(a) for a in sys.argv[1:]]:
-    text = _random_scene_text(5000 + seed)
+    text = _random_scene_text(5000 + seed, family)
     with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
         f.write(text)
     sc = R.parse_scene_file(f.name)

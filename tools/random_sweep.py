@@ -10,11 +10,12 @@ from oracle import rt_oracle as O
 from test_gpu_parity import _random_scene_text
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+family = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 r = runtime.Renderer(0)
 bad = 0
 tot_beyond = 0
 for seed in range(n):
-    text = _random_scene_text(5000 + seed)
+    text = _random_scene_text(5000 + seed, family)
     with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
         f.write(text)
     sc = R.parse_scene_file(f.name)
