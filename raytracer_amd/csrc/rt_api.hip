@@ -383,6 +383,19 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
                       d_u8 ? d_u8 + r0 * W * 3 : nullptr, st, false, &br);
         if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
         if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) {
+            if (!br.c[CNT_OVERFLOW_RAY]) {
+                // Only the shade queue overflowed, and the counters say by how much (records beyond the capacity are
+                // counted, not written): enlarge the arena to what this band needs and render it again in one piece.
+                // The arena stays that large, so the following frames of the scene do not pay for the discovery again
+                // (a deep ray tree over a 4K band needs a few GB out of 288).
+                const size_t slots = (size_t)h->sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE];
+                const size_t need = (slots + slots / 8 + kShadeFactor - 1) / kShadeFactor;
+                if (need <= kMaxArenaPixels && need > h->band_capacity) {
+                    rc = ensure_band_capacity(h, need);
+                    if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+                    continue;
+                }
+            }
             if (n == 1) {
                 // a single row outgrew the queues: enlarge them (the ray tree can double per level)
                 if (h->band_capacity * 2 > kMaxArenaPixels) {

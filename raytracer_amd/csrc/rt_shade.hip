@@ -475,59 +475,67 @@ template <int K, int NB, bool ALL_OPAQUE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
                                                  const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX],
                                                  const BoxSet& bx) {
-    if (ALL_OPAQUE) {
-        // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
-        // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
-        // from the corners; when, for every lane of the wave, either no entry can block anywhere in
-        // the tile or one entry blocks everywhere, the tile's samples are not generated at all (the
-        // jitter stream is keyed by the sample index, so skipping samples does not shift the others).
-        constexpr int T1 = 8, T2 = 8;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
-        const float cell = 65536.0f * ku;  // width of one grid cell in ur / vr units
-        uint32_t open_samples = 0;
-        // decided(i0,i1,j0,j1): 0 = undecided for some lane, 1 = decided for the whole wave (adds the open count)
-        auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
-            if (NB > 0) return false;  // boxes have no tile bound here: every sample is tested
-            const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
-            const float va = fmaf((float)j0, cell, koff), vb = fmaf((float)j1, cell, koff);
-            const float u2lo = ua * ub <= 0.f ? 0.f : fminf(ua * ua, ub * ub), u2hi = fmaxf(ua * ua, ub * ub);
-            const float v2lo = va * vb <= 0.f ? 0.f : fminf(va * va, vb * vb), v2hi = fmaxf(va * va, vb * vb);
-            const float len_lo = __builtin_amdgcn_sqrtf(lc2 + u2lo + v2lo) * 0.99999f;
-            const float len_hi = __builtin_amdgcn_sqrtf(lc2 + u2hi + v2hi) * 1.00001f;
-            bool can_block = false, must_block = false;
+    // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
+    // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
+    // from the corners; when, for every lane of the wave, either no entry can block anywhere in
+    // the tile or (opaque scenes) one entry blocks everywhere, the tile's samples are not generated
+    // at all (the jitter stream is keyed by the sample index, so skipping samples does not shift
+    // the others).  With transparent surfaces only "nothing can block" decides a tile: a blocked
+    // sample's factor depends on which entries block it.
+    constexpr int T1 = 8, T2 = 8;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
+    const float cell = 65536.0f * ku;  // width of one grid cell in ur / vr units
+    uint32_t open_samples = 0;         // opaque scenes: samples nothing blocks
+    float sum = 0.f;                   // otherwise: sum of the samples' light factors
+    // decided(i0,i1,j0,j1): false = undecided for some lane, true = decided for the whole wave (and accounted for)
+    auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
+        if (NB > 0) return false;  // boxes have no tile bound here: every sample is tested
+        const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
+        const float va = fmaf((float)j0, cell, koff), vb = fmaf((float)j1, cell, koff);
+        const float u2lo = ua * ub <= 0.f ? 0.f : fminf(ua * ua, ub * ub), u2hi = fmaxf(ua * ua, ub * ub);
+        const float v2lo = va * vb <= 0.f ? 0.f : fminf(va * va, vb * vb), v2hi = fmaxf(va * va, vb * vb);
+        const float len_lo = __builtin_amdgcn_sqrtf(lc2 + u2lo + v2lo) * 0.99999f;
+        const float len_hi = __builtin_amdgcn_sqrtf(lc2 + u2hi + v2hi) * 1.00001f;
+        bool can_block = false, must_block = false;
 #pragma unroll
-            for (int e = 0; e < K; ++e) {
-                const float bu0 = ua * Bd[e], bu1 = ub * Bd[e], cv0 = va * Cd[e], cv1 = vb * Cd[e];
-                const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
-                const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
-                const float margin = 1e-5f * (fabsf(Ad[e]) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
-                can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
-                must_block = must_block || lo > margin;
-            }
+        for (int e = 0; e < K; ++e) {
+            const float bu0 = ua * Bd[e], bu1 = ub * Bd[e], cv0 = va * Cd[e], cv1 = vb * Cd[e];
+            const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
+            const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
+            const float margin = 1e-5f * (fabsf(Ad[e]) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+            can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
+            must_block = must_block || lo > margin;
+        }
+        if (ALL_OPAQUE) {
             if (__any(can_block && !must_block)) return false;
             open_samples += must_block ? 0u : (uint32_t)((i1 - i0) * (j1 - j0));
-            return true;
-        };
-        for (int I0 = 0; I0 < N; I0 += T1) {
-            const int I1 = I0 + T1 < N ? I0 + T1 : N;
-            for (int J0 = 0; J0 < N; J0 += T1) {
-                const int J1 = J0 + T1 < N ? J0 + T1 : N;
-                if (tile_decided(I0, I1, J0, J1)) continue;
-                for (int i0 = I0; i0 < I1; i0 += T2) {
-                    const int i1 = i0 + T2 < I1 ? i0 + T2 : I1;
-                    for (int j0 = J0; j0 < J1; j0 += T2) {
-                        const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
-                        if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
-                        for (int i = i0; i < i1; ++i) {
-                            uint32_t ctr = key + (uint32_t)(i * N + j0) * 0x9E3779B9u;
-                            uint32_t mask = 0;
-                            const float urow = fmaf((float)i, cell, koff);  // left edge of row i
-                            for (int j = j0; j < j1; ++j) {
-                                const uint32_t mm = rt_mix32(ctr);
-                                ctr += 0x9E3779B9u;
-                                const float ur = fmaf((float)(mm >> 16), ku, urow);
-                                // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
-                                const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
-                                const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
+        } else {
+            if (__any(can_block)) return false;
+            sum += (float)((i1 - i0) * (j1 - j0));
+        }
+        return true;
+    };
+    for (int I0 = 0; I0 < N; I0 += T1) {
+        const int I1 = I0 + T1 < N ? I0 + T1 : N;
+        for (int J0 = 0; J0 < N; J0 += T1) {
+            const int J1 = J0 + T1 < N ? J0 + T1 : N;
+            if (tile_decided(I0, I1, J0, J1)) continue;
+            for (int i0 = I0; i0 < I1; i0 += T2) {
+                const int i1 = i0 + T2 < I1 ? i0 + T2 : I1;
+                for (int j0 = J0; j0 < J1; j0 += T2) {
+                    const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
+                    if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
+                    for (int i = i0; i < i1; ++i) {
+                        uint32_t ctr = key + (uint32_t)(i * N + j0) * 0x9E3779B9u;
+                        uint32_t mask = 0;
+                        const float urow = fmaf((float)i, cell, koff);  // left edge of row i
+                        for (int j = j0; j < j1; ++j) {
+                            const uint32_t mm = rt_mix32(ctr);
+                            ctr += 0x9E3779B9u;
+                            const float ur = fmaf((float)(mm >> 16), ku, urow);
+                            // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
+                            const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
+                            const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
+                            if (ALL_OPAQUE) {
                                 float vmax = K > 0 ? fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0])) : -INFINITY;
 #pragma unroll
                                 for (int e = 1; e < K; ++e)
@@ -541,41 +549,29 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                                 }
                                 // sign bit set <=> nothing blocks this sample
                                 mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res), 31);
+                            } else {
+                                float f = 1.f;
+#pragma unroll
+                                for (int e = 0; e < K; ++e) {
+                                    const float lin = fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]));
+                                    f = fmaf(lin, fabsf(lin), -len2) >= 0.f ? f * tr[e] : f;
+                                }
+                                if (NB > 0) {
+                                    float val[NB > 0 ? NB : 1];
+                                    box_values<NB>(bx, ur, vr, val);
+#pragma unroll
+                                    for (int b = 0; b < NB; ++b) f = val[b] >= 0.f ? f * bx.tr[b] : f;
+                                }
+                                sum += f;
                             }
-                            open_samples += (uint32_t)__popc(mask);
                         }
+                        if (ALL_OPAQUE) open_samples += (uint32_t)__popc(mask);
                     }
                 }
             }
         }
-        return (float)open_samples;
-    } else {
-        float sum = 0.f;
-        uint32_t ctr = key;
-        for (int i = 0; i < N; ++i) {
-            for (int j = 0; j < N; ++j) {
-                const uint32_t mm = rt_mix32(ctr);
-                ctr += 0x9E3779B9u;
-                const float ur = fmaf((float)__builtin_amdgcn_alignbit((uint32_t)i, mm, 16), ku, koff);
-                const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
-                const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
-                float f = 1.f;
-#pragma unroll
-                for (int e = 0; e < K; ++e) {
-                    const float lin = fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]));
-                    f = fmaf(lin, fabsf(lin), -len2) >= 0.f ? f * tr[e] : f;
-                }
-                if (NB > 0) {
-                    float val[NB > 0 ? NB : 1];
-                    box_values<NB>(bx, ur, vr, val);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) f = val[b] >= 0.f ? f * bx.tr[b] : f;
-                }
-                sum += f;
-            }
-        }
-        return sum;
     }
+    return ALL_OPAQUE ? (float)open_samples : sum;
 }
 
 template <bool ALL_OPAQUE, bool HAS_BOX>
