@@ -16,4 +16,5 @@ for it in range(6):
     st = r.render_rows_device(W, H, 0, out.data_ptr(), stream=stream, seed=it)
     if it and (best is None or st["ms_total"] < best["ms_total"]):
         best = st
+print("wave-light classes", best["wave_light"], "bands", best["bands"])
 print(f"{os.path.basename(path)} {W}x{H}: total {best['ms_total']:.3f} ms  trace {best['ms_trace']:.3f} shade {best['ms_shade']:.3f}  rays {best['total_rays']}", flush=True)
