@@ -89,11 +89,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RT_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a box with fewer GPUs than ranks -- the ranks share the
+    # visible GPUs and gather over gloo (RCCL refuses two ranks on one device); the numbers mean nothing, the code path
+    # (stripes, gather, assembly, reductions, the JSON line) is the real one
+    rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     if args.gpus != world and rank == 0 and world > 1:
@@ -110,8 +119,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def note(msg):   # progress lines of a rehearsal (a hang then names its place)
+        if rehearse:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("renderer ready")
     for i in range(args.warmup):
         dr.render(seed=i)
+    note("warm-up done")
     barrier()
     t0 = time.perf_counter()
     # the K frames are queued back to back (render, gather, assembly: no host round trip between frames) and
@@ -119,6 +134,7 @@ def main():
     for i in range(args.steps):
         dr.enqueue(seed=1000 + i)
     st = dr.finish()
+    note("timed frames done")
     rays = st["total_rays"]
     wave_light = list(st["wave_light"])
     ms_shade, flop_shade, ms_trace, ms_resolve = st["ms_shade"], st["flop_shade"], st["ms_trace"], st["ms_resolve"]
@@ -139,7 +155,7 @@ def main():
                  "frac": (bfl / 1e12) / (bms / 1e3) / FP32_VECTOR_PEAK_TFLOPS}
 
     if world > 1:
-        t = torch.tensor([dt, float(rays), ms_shade, flop_shade], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(rays), ms_shade, flop_shade], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); rays_total = float(tsum[1])

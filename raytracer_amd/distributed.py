@@ -81,6 +81,9 @@ class TileGatherer:
         self.tile = torch.zeros((self.max_rows, self.W, 3), dtype=torch.uint8, device=device)
         self.gathered = None
         self.frame = None
+        # gloo moves host memory only: device tiles are staged through the host then (rehearsals of the multi-rank
+        # path on a box with fewer GPUs than ranks; RCCL takes the device tensors as they are)
+        self.stage_host = dist.is_initialized() and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
         if self.rank == 0 and self.world > 1:
             # the tiles land in one buffer [world, max_rows, W, 3]; image row y is row source_row[y] of its flat view,
             # so the frame is assembled by ONE row gather instead of one scatter per rank
@@ -94,7 +97,13 @@ class TileGatherer:
         """Frame (H, W, 3) uint8 on rank 0, None elsewhere; with one rank, the tile itself."""
         if self.world == 1:
             return self.tile[: len(self.my_rows)]
-        self.dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
+        if self.stage_host:
+            host = [self.torch.empty(self.tile.shape, dtype=self.torch.uint8) for _ in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(self.tile.cpu(), host, dst=0, group=self.group)
+            if self.rank == 0:
+                self.buffer.copy_(self.torch.stack(host))
+        else:
+            self.dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
         if self.rank != 0:
             return None
         self.torch.index_select(self.buffer.view(self.world * self.max_rows, self.W, 3), 0, self.source_row, out=self.frame)
