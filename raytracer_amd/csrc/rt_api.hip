@@ -292,10 +292,6 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
-        // one work item per 64-hit chunk.  Splitting a chunk's lights over several items was measured
-        // slower even on small bands: the items of one hit run concurrently and their float64
-        // accumulator updates collide on the same addresses.
-        sa.light_groups = 1;
         sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
         sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);

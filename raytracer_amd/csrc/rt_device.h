@@ -171,7 +171,6 @@ struct ShadeArgs {
     int32_t has_box;     // scene contains at least one box
     int32_t all_opaque;  // every surface's material has transparency == 0
     int32_t no_cull;     // 1: always run the generic per-sample loop (no per-light classification)
-    int32_t light_groups; // work items per 64-hit chunk in the fast kernel (1 .. n_lights)
     uint32_t* work;      // shared work counter of the fast kernel (zeroed per band)
     uint32_t* work2;     // shared work counter of the deferred kernel
     uint2* deferred;     // (first hit of a 64-hit chunk, light) pairs left to the generic loop

@@ -594,11 +594,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
     // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
     // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
-    // work item = (64-hit chunk, light group): group g of G owns lights g, g+G, ...  The host picks
-    // G = 1 for big bands (one accumulator update per hit) and up to L for small ones, where the
-    // time of one item decides the tail of the launch
-    const uint32_t G = (uint32_t)a.light_groups;
-    const uint32_t n_items = ((count + 63u) >> 6) * G;
+    // work item = one 64-hit chunk with all its lights (splitting a chunk by light was measured slower: the hit is
+    // loaded and its accumulators updated once per part, and short items saturate the shared work counter)
+    const uint32_t n_items = (count + 63u) >> 6;
     uint32_t grab = 0, grab_end = 0;
     for (;;) {
         if (grab >= grab_end) {
@@ -613,8 +611,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
         const uint32_t item = grab;
         grab += 1u;
         if (item >= n_items) { grab = grab_end; continue; }
-        const uint32_t base = (item / G) << 6;
-        const int l_first = (int)(item % G);
+        const uint32_t base = item << 6;
         HitRec h;
         bool active;
         if (!load_chunk(a.q, base, count, lane, h, active)) continue;
@@ -629,7 +626,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
         const float pfuzz_hit = 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z));
 
         f3 color = F3(0.f, 0.f, 0.f);
-        for (int l = l_first; l < L; l += (int)G) {
+        for (int l = 0; l < L; ++l) {
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? 0xFFu : 0u;  // surfaces the generic loop has to test for this (wave, light)
