@@ -223,11 +223,20 @@ __device__ __forceinline__ bool surface_blocks(const SurfF& sf, f3 P, f3 w, floa
 }
 
 template <bool BATCH>
-__device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, float dist, int own_id, f3 nrm, uint32_t flags) {
+__device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, float dist, int own_id, f3 nrm, uint32_t flags,
+                                               unsigned long long reach_mask) {
     const SceneGrid& g = a.grid;
     float f = 1.f;
     if (!g.cell_start) {
         const int S = a.fp.n_surfaces;
+        if (S <= 64) {   // only the surfaces some lane of the wave can reach from this light (wave-uniform mask)
+            for (unsigned long long m = reach_mask & (S == 64 ? ~0ull : (1ull << S) - 1ull); m; m &= m - 1ull) {
+                const int s = (int)__builtin_ctzll(m);
+                const SurfF sf = a.surf[s];
+                f = surface_blocks<BATCH>(sf, P, w, dist, s == own_id, nrm, flags) ? f * sf.transp : f;
+            }
+            return f;
+        }
         for (int s = 0; s < S; ++s) {
             const SurfF sf = a.surf[s];
             f = surface_blocks<BATCH>(sf, P, w, dist, s == own_id, nrm, flags) ? f * sf.transp : f;
@@ -328,16 +337,50 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             if (lt.point_path) {
                 // ---- one ray to the light centre (ray_tracer.py:36-48)
                 const float dist = lc2 * linv;
-                ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags);
+                ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags, ~0ull);
             } else {
                 // ---- light basis (light.py:24-30) and the N x N grid (light.py:51-63)
                 const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
                 const f3 right = normalize(cross(ldir, perp));
                 const f3 up = normalize(cross(right, ldir));
                 const uint32_t key = rt_grid_key(a.fp.seed_key, gpix, node, (uint32_t)l);
+                // Scenes of 9..64 surfaces (no grid): which surfaces can any of the wave's 64 hits reach from this light at
+                // all?  All N*N samples lie within rho of the light centre, so a surface whose bounding sphere stays clear of
+                // the widened segment hit->light is skipped for the whole wave -- and a wave that reaches nothing skips the
+                // sample loop altogether (ratio = 1).  A light whose Phong terms vanish for a hit needs no surfaces for it.
+                unsigned long long reach_mask = ~0ull;
+                const int S = a.fp.n_surfaces;
+                if (!a.grid.cell_start && S <= 64 && !a.no_cull) {
+                    reach_mask = 0ull;
+                    const float llen = lc2 * linv;
+                    const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + llen);
+                    const float inv_lc2 = linv * linv;
+                    const float ndl0 = dot(nrm, ldir);
+                    const float rv0 = 2.f * ndl0 * dot(nrm, view) - dot(ldir, view);
+                    const bool lit = active && (ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f));
+                    for (int s = 0; s < S; ++s) {
+                        const SurfF sf = a.surf[s];
+                        bool reach;
+                        if (sf.type == RT_SURF_PLANE) {
+                            const f3 n = F3(sf.a.x, sf.a.y, sf.a.z);
+                            const float hh = sf.a.w - dot(P, n);
+                            const float ah = fabsf(hh), dn0 = dot(lrel, n) * (hh < 0.f ? -1.f : 1.f);
+                            reach = !((ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0)));
+                        } else {
+                            const bool sph = sf.type == RT_SURF_SPHERE;
+                            const f3 oc = P - (sph ? F3(sf.a.x, sf.a.y, sf.a.z) : F3(sf.c.x, sf.c.y, sf.c.z));
+                            const float rad = sph ? sf.c.x : sf.c.w;
+                            const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
+                            const f3 q = oc + lrel * t;
+                            const float rr = rad + rho;
+                            reach = !(dot(q, q) > rr * rr * 1.0002f);
+                        }
+                        if (__any(lit && (reach || s == own_id))) reach_mask |= 1ull << s;
+                    }
+                }
                 float sum = 0.f;
                 uint32_t s_idx = 0;
-                for (int i = 0; i < N; ++i) {
+                for (int i = 0; i < N && reach_mask; ++i) {
                     for (int j = 0; j < N; ++j, ++s_idx) {
                         uint32_t ub, vb;
                         rt_sample_bits(key, s_idx, ub, vb);
@@ -348,10 +391,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         const float dinv = __frsqrt_rn(d2);
                         const f3 w = sv * dinv;
                         const float dist = d2 * dinv;
-                        sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags);
+                        sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
                     }
                 }
-                ratio = sum * inv_n2;
+                ratio = reach_mask ? sum * inv_n2 : 1.f;
             }
             // ---- intensity (ray_tracer.py:105) and Phong terms (:157-170)
             const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;

@@ -512,3 +512,18 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["scaling"] == "strong"
     assert d["config"]["rays_per_frame"] == 14358303438.0      # both halves of the 4K pool N = 16 frame
     assert d["value"] > 0 and d["ms_per_step"] > 0
+
+
+def test_mid_size_scene_uses_the_reach_mask(renderer, oracle, tmp_path):
+    """32 surfaces: no grid, no register-resident kernel -- the any-size kernel tests, per (wave, light), only the
+    surfaces some hit of the wave can reach.  Same counters and image as the oracle, and as RT_FLAG_NO_CULL."""
+    sc = R.parse_scene_file(write_scene(tmp_path, _crowded_scene_text(22, 8, seed=3).replace("set 0.3 0.4 0.6 2 3", "set 0.3 0.4 0.6 4 3")))
+    assert len(sc.surfaces) == 32
+    w, h = 128, 72
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=2, threads=THREADS)
+    _, masked, st = renderer.render_rows(w, h, seed=2)
+    _, brute, _ = renderer.render_rows(w, h, seed=2, flags=2)
+    assert counters_of(st) == cnt
+    assert_parity(masked, ref)
+    assert CI.metrics(brute, masked)["max_abs_diff"] <= 1
