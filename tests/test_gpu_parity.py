@@ -420,7 +420,8 @@ def _random_scene_text(seed, family=0):
     transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5.
     family 1: mostly boxes, N in 4..8, wider lights."""
     rng = np.random.default_rng(seed)
-    p_sphere, n_lo, n_hi, r_hi = (0.6, 1, 5, 2.5) if family == 0 else (0.25, 4, 9, 4.0)
+    p_sphere, n_lo, n_hi, r_hi = (0.6, 1, 5, 2.5) if family == 0 else ((0.25, 4, 9, 4.0) if family == 1 else (0.6, 2, 5, 2.5))
+    s_lo, s_hi = (2, 13) if family < 2 else (15, 41)   # family 2: 16..42 surfaces (the any-size kernel's reach mask)
 
     def q(lo, hi):
         return round(float(rng.uniform(lo, hi)) * 256.0) / 256.0
@@ -437,7 +438,7 @@ def _random_scene_text(seed, family=0):
     lines.append(f"pln 0 1 0 {q(-1, 0)!r} {int(rng.integers(1, n_mat + 1))}")
     if rng.random() < 0.5:
         lines.append(f"pln {q(-0.3, 0.3)!r} {q(-0.2, 0.2)!r} 1 {q(-8, -4)!r} {int(rng.integers(1, n_mat + 1))}")
-    for _ in range(int(rng.integers(2, 13))):
+    for _ in range(int(rng.integers(s_lo, s_hi))):
         m = int(rng.integers(1, n_mat + 1))
         if rng.random() < p_sphere:
             lines.append(f"sph {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.2, 1.0)!r} {m}")
