@@ -415,6 +415,33 @@ def test_enqueued_frames_equal_synchronous_frames(renderer):
         renderer.enqueue_rows_device(3840, 2161, 0, bufs[0].data_ptr(), stream=stream)
 
 
+def test_frame_stream_delivers_every_frame_to_the_host_in_order(renderer):
+    """frames.FrameStream: copies overlapped with the next frame's kernels; every frame arrives, in order, equal to
+    the synchronous frame of the same seed; ring sizes 2, 3 and 8 behave alike."""
+    from raytracer_amd.frames import FrameStream
+    w, h = 160, 90
+    renderer.set_scene(scene("transparency_v7"))
+    seeds = list(range(13))
+    want = [renderer.render_rows(w, h, seed=s, want_f32=False)[1] for s in seeds]
+    for depth in (2, 3, 8):
+        fs = FrameStream(renderer, w, h, depth=depth)
+        got = []
+        for s in seeds:
+            done = fs.submit(s)
+            if done is not None:
+                got.append(done.copy())
+        got += [d.copy() for d in fs.drain()]
+        st = fs.stats()
+        assert len(got) == len(seeds) and st["primary_rays"] == len(seeds) * w * h
+        for a, b in zip(want, got):
+            m = CI.metrics(a, b)
+            assert m["max_abs_diff"] <= 1 and m["within_1lsb"] == 1.0
+        # consecutive seeds differ (soft-shadow jitter), so an out-of-order delivery would not pass unnoticed
+        assert any(CI.metrics(want[i], want[i + 1])["max_abs_diff"] > 1 for i in range(len(seeds) - 1))
+    with pytest.raises(ValueError):
+        FrameStream(renderer, w, h, depth=9)
+
+
 def _random_scene_text(seed, family=0):
     """Small random scenes: 3..14 surfaces of all three kinds (some touching or overlapping), reflective and
     transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5.
