@@ -8,7 +8,9 @@
 A step is one full frame of scenes/pool_n16.txt (pool geometry, 16x16 soft-shadow
 grid, max_recursions 10) with the scene already resident on the GPU; the frame is
 split into interleaved row stripes over the ranks and the uint8 tiles are gathered
-to rank 0 over RCCL inside the timed region.  The total frame is fixed, so scaling
+to rank 0 over RCCL inside the timed region.  The K timed frames are queued and
+alternate over --pipelines renderer handles (streams) per rank, so consecutive
+frames overlap at their ends.  The total frame is fixed, so scaling
 is strong.  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -73,6 +75,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="pool_n16_4k", choices=sorted(WORKLOADS))
+    ap.add_argument("--pipelines", type=int, default=2,
+                    help="renderer handles (each with a stream of its own) the queued frames alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true",
                     help="skip the RT_FLAG_NO_CULL frames after the timed region (profiling runs: keeps per-kernel averages clean)")
@@ -112,7 +116,7 @@ def main():
     scene = R.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".txt"))
     renderer = runtime.Renderer(local_rank)
     renderer.set_scene(scene)
-    dr = DistributedRenderer(renderer, W, H, flags=2 if args.no_cull else 0)
+    dr = DistributedRenderer(renderer, W, H, flags=2 if args.no_cull else 0, pipelines=args.pipelines)
 
     def barrier():
         if world > 1:
@@ -124,8 +128,10 @@ def main():
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     note("renderer ready")
+    isolated = None   # kernel times of a frame rendered alone (warm-up frames run one at a time on one stream)
     for i in range(args.warmup):
-        dr.render(seed=i)
+        _, isolated = dr.render(seed=i)
+    dr.prepare()      # every pipeline has rendered once before the clock starts
     note("warm-up done")
     barrier()
     t0 = time.perf_counter()
@@ -188,6 +194,7 @@ def main():
                                    "max_recursions 10)" if args.workload == "pool_n16_4k"
                        else f"scenes/{scene_name}.txt at {W}x{H}",
                        "rays_per_frame": rays_total / steps, "partition": f"row stripes x{world}, uint8 gather to rank 0",
+                       "pipelines": args.pipelines,
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},
             "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "-"], wave_light)),
             "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "resolve": ms_resolve / steps},
@@ -199,9 +206,16 @@ def main():
                                  "time; it can exceed the peak because the kernel reaches the same result without "
                                  "performing that arithmetic (per-light surface classification, 3-FMA linear tests, skipped sample "
                                  "tiles); brute_force = the same frame and flop count with every ray tested against every "
-                                 "surface (RT_FLAG_NO_CULL). "
+                                 "surface (RT_FLAG_NO_CULL). With pipelines > 1 the timed frames alternate over that many "
+                                 "streams and their kernels overlap, so the HIP-event duration of a launch (achieved, "
+                                 "kernel_ms_per_frame_rank0) includes time shared with the other stream's kernels; isolated = "
+                                 "the same launch of the last warm-up frame, which runs alone. "
                                  "valu_issue = measured VALU instructions per SIMD cycle of k_shade_fast (rocprofv3 PMC, "
                                  "profiles/) against the v_fma_f32 issue ceiling measured on this chip.",
+                         "isolated": None if not isolated or isolated["ms_shade"] <= 0 else {
+                             "shade_ms_per_frame": isolated["ms_shade"],
+                             "achieved": (isolated["flop_shade"] / 1e12) / (isolated["ms_shade"] / 1e3), "unit": "TFLOP/s",
+                             "frac": (isolated["flop_shade"] / 1e12) / (isolated["ms_shade"] / 1e3) / FP32_VECTOR_PEAK_TFLOPS},
                          "brute_force": brute,
                          "valu_issue": {"cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
                                         "ceiling_cycles_v_fma_f32": 4.0,

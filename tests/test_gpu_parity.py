@@ -442,6 +442,37 @@ def test_frame_stream_delivers_every_frame_to_the_host_in_order(renderer):
         FrameStream(renderer, w, h, depth=9)
 
 
+def test_two_pipelines_give_the_frames_of_one(renderer):
+    """distributed.DistributedRenderer with two pipelines (two handles, two streams): queued frames alternate over
+    them, overlap at their ends, and equal the frames of the synchronous call; statistics add up."""
+    from raytracer_amd.distributed import DistributedRenderer
+    w, h = 320, 180
+    renderer.set_scene(scene("pool"))
+    seeds = list(range(7))
+    want, rays = [], 0
+    for s in seeds:
+        _, u8, st = renderer.render_rows(w, h, seed=s, want_f32=False)
+        want.append(u8); rays += st["total_rays"]
+    dr = DistributedRenderer(renderer, w, h, pipelines=2)
+    first, st0 = dr.render(seed=0)
+    assert CI.metrics(want[0], first.cpu().numpy())["within_1lsb"] == 1.0 and st0["total_rays"] > 0
+    got = []
+    for i in range(0, len(seeds), 2):        # a frame tensor is reused two frames later: collect in pairs
+        frames = [dr.enqueue(seed=s) for s in seeds[i:i + 2]]
+        st = dr.finish()
+        got += [f.cpu().numpy() for f in frames]
+        rays -= st["total_rays"]
+    assert rays == 0
+    assert len(got) == len(seeds)
+    for u8, g in zip(want, got):
+        m = CI.metrics(u8, g)
+        assert m["max_abs_diff"] <= 1 and m["within_1lsb"] == 1.0
+    a, b = dr.lanes[0].stream, dr.lanes[1].stream
+    assert a is not None and b is not None and a.cuda_stream != b.cuda_stream
+    with pytest.raises(ValueError):
+        DistributedRenderer(renderer, w, h, pipelines=0)
+
+
 def _random_scene_text(seed, family=0):
     """Small random scenes: 3..14 surfaces of all three kinds (some touching or overlapping), reflective and
     transparent materials, 1..3 lights with and without soft shadows, N in 1..4, depth 1..5.

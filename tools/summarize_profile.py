@@ -25,6 +25,9 @@ os.makedirs(dst, exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "trace_isolated", "*", "*_kernel_stats.csv"))
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats_isolated.csv"))
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
