@@ -196,7 +196,7 @@ def main():
                        "rays_per_frame": rays_total / steps, "partition": f"row stripes x{world}, uint8 gather to rank 0",
                        "pipelines": args.pipelines,
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},
-            "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "-"], wave_light)),
+            "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "float64_pairs"], wave_light)),
             "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "resolve": ms_resolve / steps},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,

@@ -4,7 +4,9 @@
 
 The float64 ray-tree kernel and the host code that derives scene constants are
 compiled with floating-point contraction off (their fused multiply-adds are
-explicit); the FP32 shading kernel is compiled with contraction on.
+explicit); the FP32 shading kernels are compiled with contraction on, except for
+the float64 functions of rt_exact.h, which switch it off by pragma (hence
+fast-honor-pragmas: plain "fast" ignores the pragma).
 """
 from __future__ import annotations
 
@@ -22,11 +24,11 @@ ARCH = "gfx950"
 SOURCES = [
     # (file, extra flags)
     ("rt_trace.hip", ["-ffp-contract=off"]),
-    ("rt_shade.hip", ["-ffp-contract=fast"]),
+    ("rt_shade.hip", ["-ffp-contract=fast-honor-pragmas"]),  # FP32 code fuses; rt_exact.h switches it off for its float64 chain
     ("rt_api.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
-HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(HERE, "..", "include", "rt_amd.h")]
+HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_exact.h"), os.path.join(HERE, "..", "include", "rt_amd.h")]
 
 
 def hipcc():

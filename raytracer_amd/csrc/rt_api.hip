@@ -63,6 +63,7 @@ struct rt_handle {
     SurfF* d_surff = nullptr;
     MatF* d_mat = nullptr;
     LightF* d_light = nullptr;
+    double* d_light64 = nullptr;         // float64 position xyz + radius per light (exact own-sphere evaluation)
     int has_box = 0, all_opaque = 1;
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
@@ -79,6 +80,8 @@ struct rt_handle {
     // uniform grid over the bounded surfaces (large scenes)
     SceneGrid grid{};
     uint32_t* d_grid_mem = nullptr;
+    float exact_min = 1e-4f;         // RT_EXACT_MIN: see ShadeArgs::exact_min
+    size_t exact_list = 0;           // RT_EXACT_LIST: initial length of the float64 pair list (test hook; 0 = two per pixel)
     int grid_override = -1;          // RT_GRID: -1 automatic (more than kGridMinSurfaces surfaces), 0 never, 1 always
     // run-to-completion tail of the ray tree (k_trace_tail)
     bool both_children = false;      // some material spawns a reflection and a transparency child
@@ -89,6 +92,9 @@ struct rt_handle {
     size_t accum_zero_prefix = 0;    // accumulator values [0, prefix) are known to be zero (k_resolve clears what it reads)
     std::vector<int32_t> rows_on_device;  // what d_row_y holds
     uint2* d_deferred = nullptr;
+    uint2* d_exact = nullptr;            // (slot, light) list of k_shade_exact
+    uint32_t exact_capacity = 0;
+    size_t exact_want = 0;               // pairs a frame asked for when the list was too short (it is then rebuilt that large)
     int arena_lights = 0;
     bool arena_has_rays = false;     // the arena holds full-size ray queues
     int32_t* d_row_y = nullptr;
@@ -150,7 +156,8 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const int lights = h->L > 0 ? h->L : 1;
     // the ping-pong ray queues are only needed when some level has a launch of its own
     const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
-    if (pixels <= h->band_capacity && lights <= h->arena_lights && (!need_rays || h->arena_has_rays)) return RT_OK;
+    if (pixels <= h->band_capacity && lights <= h->arena_lights && (!need_rays || h->arena_has_rays) &&
+        h->exact_want <= h->exact_capacity) return RT_OK;
     if (pixels < h->band_capacity) pixels = h->band_capacity;
     if (pixels < kMinArenaPixels) pixels = kMinArenaPixels;  // head-room for deep ray trees of small frames
     free_frame_buffers(h);
@@ -158,10 +165,12 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     auto al = [](size_t b) { return (b + 255) / 256 * 256; };
     size_t bytes = 0;
     bytes += 2 * (4 * al(rcap * 16) + al(rcap * 4));     // two ray queues
-    bytes += 4 * al(scap * 16);                         // shade queue
+    bytes += 4 * al(scap * 16) + al(scap * 24);          // shade queue (+ float64 hit points)
     bytes += al(pixels * 3 * 8);                        // accumulators
     const size_t dcap = (scap / 64 + 1) * (size_t)lights; // every (64-hit chunk, light) pair at most once
     bytes += al(dcap * sizeof(uint2));
+    const size_t ecap = std::max(h->exact_list ? h->exact_list : scap / 2, h->exact_want); // pairs needing float64 are rare; a frame that needs more says so
+    bytes += al(ecap * sizeof(uint2));
     void* base = nullptr;
     hipError_t e = hipMalloc(&base, bytes);
     if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes for frame queues failed");
@@ -178,10 +187,13 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     ShadeQueue& s = h->sq;
     s.r0 = (float4*)take(scap * 16); s.r1 = (float4*)take(scap * 16); s.r2 = (float4*)take(scap * 16);
     s.r3 = (uint4*)take(scap * 16);
+    s.p64 = (double*)take(scap * 24);
     s.count = h->d_qcounts + 2;
     s.capacity = (uint32_t)scap;
     h->d_accum = (double*)take(pixels * 3 * 8);
     h->d_deferred = (uint2*)take(dcap * sizeof(uint2));
+    h->d_exact = (uint2*)take(ecap * sizeof(uint2));
+    h->exact_capacity = (uint32_t)std::min<size_t>(ecap, 0x7FFFFFFFu);
     h->band_capacity = pixels;
     h->arena_lights = lights;
     h->arena_has_rays = need_rays;
@@ -288,12 +300,15 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     if (!debug) {
         ShadeArgs sa{};
         sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq; sa.grid = h->grid;
+        sa.surf64 = h->d_surf; sa.light64 = h->d_light64;
         sa.accum = h->d_accum; sa.npix = pixels; sa.counters = h->d_counters;
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
         sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
         sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
+        sa.exact_min = h->exact_min;
+        sa.exact = h->d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->exact_capacity; sa.work3 = h->d_qcounts + 47;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
@@ -318,6 +333,7 @@ void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, floa
     s.depth_cut += c[CNT_DEPTH_CUT]; s.shaded_points += c[CNT_SHADED];
     s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_resolve += ms_resolve;
     for (int k = 0; k < 7; ++k) s.wave_light[k] += c[CNT_WL_NONE + k];
+    s.wave_light[7] += c[CNT_EXACT];
     s.bands += 1;
     s.rows_rendered += rows;
     s.shadow_rays += (uint64_t)std::llround((double)c[CNT_SHADED] * h->shadow_rays_per_hit);
@@ -335,7 +351,7 @@ int collect_oldest(rt_handle* h) {
     HIP_TRY(h, hipEventElapsedTime(&t1, e.ev[1], e.ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
-    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE]) h->async_overflow = true;
+    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->exact_capacity) h->async_overflow = true;
     add_band_stats(h, h->async_sum, e.counters, t0, t1, t2, e.rows);
     h->async_sum.ms_total += all;
     return RT_OK;
@@ -378,6 +394,15 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
         rc = run_band(h, p, rows.data() + r0, (int)n, d_f32 ? d_f32 + r0 * W * 3 : nullptr,
                       d_u8 ? d_u8 + r0 * W * 3 : nullptr, st, false, &br);
         if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+        if (br.c[CNT_EXACT] > h->exact_capacity && !br.c[CNT_OVERFLOW_RAY] && !br.c[CNT_OVERFLOW_SHADE]) {
+            // more (hit, light) pairs needed their own sphere in float64 than the list holds (a camera inside a glass
+            // ball): the counter says how many; rebuild the arena with a list of that size and render the band again
+            h->exact_want = (size_t)br.c[CNT_EXACT] + (size_t)br.c[CNT_EXACT] / 4 + 1024;
+            if (h->exact_want > 0x7FFFFFFFu) { (void)hipEventDestroy(e_end); return fail(h, RT_ERR_QUEUE, "float64 pair list beyond 2^31 entries"); }
+            rc = ensure_band_capacity(h, h->band_capacity);
+            if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+            continue;
+        }
         if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) {
             if (!br.c[CNT_OVERFLOW_RAY]) {
                 // Only the shade queue overflowed, and the counters say by how much (records beyond the capacity are
@@ -515,6 +540,8 @@ int rt_create(int device, rt_handle** out) {
     // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d on (default: from the camera rays)
     if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
     if (const char* e = std::getenv("RT_GRID")) h->grid_override = std::atoi(e);  // test hook: force the grid on / off
+    if (const char* e = std::getenv("RT_EXACT_MIN")) h->exact_min = (float)std::atof(e);
+    if (const char* e = std::getenv("RT_EXACT_LIST")) h->exact_list = (size_t)std::max(1ll, std::atoll(e));
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
         long v = std::atol(e);
         if (v > 0) h->max_band_pixels = (size_t)v;
@@ -536,7 +563,7 @@ void rt_destroy(rt_handle* h) {
         if (e.counters) (void)hipHostFree(e.counters);
     }
     free_frame_buffers(h);
-    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_counters,
+    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_counters,
                     (void*)h->stack_mem, (void*)h->d_grid_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
@@ -622,12 +649,15 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     std::vector<LightF> lights((size_t)std::max(L, 1));
     std::memset(lights.data(), 0, sizeof(LightF) * lights.size());
     double rays_per_hit = 0;
+    std::vector<double> light64((size_t)std::max(L, 1) * 4, 0.0);
     for (int l = 0; l < L; ++l) {
         const double* q = d->light_param;
         LightF& t = lights[l];
         for (int c = 0; c < 3; ++c) { t.pos[c] = (float)q[c * L + l]; t.col[c] = (float)q[(3 + c) * L + l]; }
         t.spec = (float)q[6 * L + l]; t.shadow = (float)q[7 * L + l]; t.radius = (float)q[8 * L + l];
         t.point_path = (q[7 * L + l] == 0 || d->n_shadow == 1) ? 1 : 0;  // ray_tracer.py:36
+        for (int c = 0; c < 3; ++c) light64[(size_t)l * 4 + c] = q[c * L + l];
+        light64[(size_t)l * 4 + 3] = q[8 * L + l];
         rays_per_hit += t.point_path ? 1.0 : (double)d->n_shadow * d->n_shadow;
     }
 
@@ -645,7 +675,7 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     cam.up[0] = up.x; cam.up[1] = up.y; cam.up[2] = up.z;
     cam.sdist = d->cam_screen_dist; cam.swidth = d->cam_screen_width;
 
-    for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light}) {
+    for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light, (void**)&h->d_light64}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -658,6 +688,8 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_surff, sf.data(), sizeof(SurfF) * sf.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_mat, mats.data(), sizeof(MatF) * mats.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_light, lights.data(), sizeof(LightF) * lights.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMalloc(&h->d_light64, sizeof(double) * light64.size()));
+    HIP_TRY(h, hipMemcpy(h->d_light64, light64.data(), sizeof(double) * light64.size(), hipMemcpyHostToDevice));
     int rc = build_grid(h, sd, S);
     if (rc != RT_OK) return rc;
     h->S = S; h->M = M; h->L = L; h->N = d->n_shadow; h->R = d->max_rec;

@@ -83,6 +83,12 @@ struct RayQueue {
 #define HF_CDOT_POS 2u     // sphere: dot(oc,oc) - r*r > 0    (sphere.py:38)  -> same, single-ray path
 #define HF_BOX_OUTSIDE 4u  // box: hit point lies strictly outside its face plane -> single-ray path not blocked
 #define HF_NO_OWN 8u       // degenerate hit (zero normal): no own-surface rule
+// A hit on a sphere with c > 0 (either form above): a shadow ray that points INTO that sphere has its near root at
+// t1 = c/|b| ~ 1e-16.  The reference keeps it (and so sees no blocker) only if its float64 quadratic still resolves
+// it: sqrt(fl(b*b - 4ac)) < |b|, which depends on the last bits of b once 4ac is within a few ulps of b*b -- the
+// normal case, since c is a rounding residue of one or two quanta.  Such hits carry their float64 hit point
+// (ShadeQueue::p64) and the shading kernels evaluate the own-sphere quadratic of inward samples in float64.
+#define HF_EXACT 16u
 
 // Slots [0, base) belong to the camera rays: the ray of enumeration index i (8 x 8 pixel tiles, see
 // rt_trace.hip) owns slot i, so a 64-slot chunk is one pixel tile; a slot whose ray left the scene or
@@ -94,6 +100,7 @@ struct ShadeQueue {
     float4 *r1;   // normal yz (stored outward normal), view xy (direction towards the ray origin)
     float4 *r2;   // view z, weight rgb = throughput * (1 - transparency)
     uint4 *r3;    // LOCAL pixel index inside the band, GLOBAL pixel index y*W+x (jitter key), node, surface | flags << 24
+    double *p64;  // float64 hit point, 3 per slot; written only for HF_EXACT hits
     uint32_t* count;
     uint32_t capacity;
     uint32_t base;
@@ -113,7 +120,9 @@ struct HitDebug {
 enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_RAY, CNT_OVERFLOW_SHADE, CNT_WORK,
        // how the shading kernel resolved each (wave, light): ratio = 1 without sampling, compact loop
        // with 1..4 linear tests, generic loop (some lane needs it / more than 4 candidates), single-ray path
-       CNT_WL_NONE, CNT_WL_K1, CNT_WL_K2, CNT_WL_K3, CNT_WL_K4, CNT_WL_GENERIC, CNT_WL_POINT, CNT_N };
+       CNT_WL_NONE, CNT_WL_K1, CNT_WL_K2, CNT_WL_K3, CNT_WL_K4, CNT_WL_GENERIC, CNT_WL_POINT,
+       CNT_EXACT,  // (hit, light) pairs evaluated by k_shade_exact
+       CNT_N };
 
 struct FrameParams {
     int32_t width, height;
@@ -175,9 +184,16 @@ struct ShadeArgs {
     uint32_t* work2;     // shared work counter of the deferred kernel
     uint2* deferred;     // (first hit of a 64-hit chunk, light) pairs left to the generic loop
     uint32_t* deferred_count;
+    uint2* exact;        // (shade slot, light) pairs whose own-sphere samples need float64 (k_shade_exact), RT_NULL_HIT = void
+    uint32_t* exact_count;
+    uint32_t exact_capacity;
+    uint32_t* work3;     // shared work counter of k_shade_exact
+    float exact_min;     // a back-lit pair goes to k_shade_exact only if its specular term can exceed this (full scale = 1)
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;
+    const SurfD* surf64; // float64 surfaces and lights (position xyz, radius: 4 per light) for HF_EXACT hits
+    const double* light64;
     SceneGrid grid;      // used by the any-size kernel
     ShadeQueue q;
     double* accum;       // planar [3][npix]

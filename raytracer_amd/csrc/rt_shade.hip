@@ -27,6 +27,8 @@
 #include "../../include/rt_amd.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
+#include "rt_exact.h"
+
 #define SHADE_BLOCK 256
 
 struct f3 { float x, y, z; };
@@ -311,6 +313,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
     const int L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
+    const double inv_n64 = (N & (N - 1)) == 0 ? 1.0 / (double)N : 0.0;   // exact reciprocal of a power of two (rt_exact.h)
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
@@ -324,7 +327,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         const uint32_t gpix = hr.gpix, node = hr.node, flags = hr.flags;
         const uint32_t meta = (uint32_t)hr.own_id;
         const int own_id = (flags & HF_NO_OWN) ? -1 : hr.own_id;
-        const MatF m = a.mat[a.surf[meta & 0xFFFFFFu].mat];
+        const SurfF own_sf = a.surf[meta & 0xFFFFFFu];
+        const MatF m = a.mat[own_sf.mat];
+        // own sphere with c > 0: inward shadow rays are decided in float64 (rt_exact.h)
+        const bool exact = active && own_id >= 0 && (flags & HF_EXACT);
+        const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);
+        const float inward_limit = -0.2f * own_sf.c.x;   // see k_shade_deferred
+        const double* p64 = a.q.p64 + (size_t)(base + lane) * 3;
 
         f3 color = F3(0.f, 0.f, 0.f);
         for (int l = 0; l < L; ++l) {
@@ -338,6 +347,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 // ---- one ray to the light centre (ray_tracer.py:36-48)
                 const float dist = lc2 * linv;
                 ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags, ~0ull);
+                if (exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
+                    rtx::own_sphere_blocks_centre(p64, a.light64 + (size_t)l * 4, a.surf64[own_id]))
+                    ratio *= own_sf.transp;
             } else {
                 // ---- light basis (light.py:24-30) and the N x N grid (light.py:51-63)
                 const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
@@ -378,6 +390,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         if (__any(lit && (reach || s == own_id))) reach_mask |= 1ull << s;
                     }
                 }
+                const bool exact_b = exact && (flags & HF_CBATCH_POS) && reach_mask != 0ull;
+                rtx::OwnSphere os;
+                if (exact_b) os = rtx::own_sphere_setup(p64, a.light64 + (size_t)l * 4);
                 float sum = 0.f;
                 uint32_t s_idx = 0;
                 for (int i = 0; i < N && reach_mask; ++i) {
@@ -391,7 +406,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         const float dinv = __frsqrt_rn(d2);
                         const f3 w = sv * dinv;
                         const float dist = d2 * dinv;
-                        sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
+                        float f = shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
+                        if (exact_b && dot(w, ov) < inward_limit &&
+                            rtx::own_sphere_blocks_sample(os, a.light64 + (size_t)l * 4, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
+                            f *= own_sf.transp;
+                        sum += f;
                     }
                 }
                 ratio = reach_mask ? sum * inv_n2 : 1.f;
@@ -673,6 +692,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? 0xFFu : 0u;  // surfaces the generic loop has to test for this (wave, light)
+            bool need_exact = false;                   // this lane's pair also goes to k_shade_exact (correction)
             float ratio = 1.f;
             const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
             const float lc2 = dot(lrel, lrel);
@@ -766,6 +786,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                     }
                 }
                 A[SMALL_MAX] = -INFINITY; B[SMALL_MAX] = 0.f; C[SMALL_MAX] = 0.f;
+                // own sphere with c > 0 and a sample that may enter it steeply: k_shade_exact decides those samples in float64.
+                // Such a light lies behind the tangent plane (no diffuse term); when its specular term is below 1e-4 of
+                // full scale (0.03 LSB) for every channel, whatever the shadow ratio, the float64 answer cannot show.
+                // (samples steeper than cos 0.2 only: see inward_limit in k_shade_deferred)
+                // The samples span a square of edge `radius` in (right, up): sv.ov is smallest in a corner, |sv| >= llen.
+                if (own_sphere && (h.flags & HF_CBATCH_POS) && lit && active &&
+                    dot(lrel, ov) - (0.5002f * lt.radius + 1e-6f) * (fabsf(dot(right, ov)) + fabsf(dot(up, ov))) <
+                        own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + rho))) {
+                    bool shows = ndl0 > 0.f;
+                    if (!shows) {
+                        const float sp = rv0 > 0.f ? pow_pos(rv0, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+                        const float cmax = fmaxf(fmaxf(m.ks[0] * lt.col[0] * h.wgt.x, m.ks[1] * lt.col[1] * h.wgt.y), m.ks[2] * lt.col[2] * h.wgt.z);
+                        shows = sp * lt.spec * lt.shadow * cmax > a.exact_min;
+                    }
+                    need_exact = shows;
+                }
                 if (own_sph_blocks && lit) {
                     const float r = own_sf.c.x;
                     const float dl = dot(lrel, ov);
@@ -790,6 +826,19 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 }
                 const int nb = __popc(bcand);
                 defer = __any(gen) || k > KMAX || nb > NBMAX;
+                if (defer) need_exact = false;   // the generic kernel lists those lanes itself
+                const unsigned long long em = __ballot(need_exact);
+                if (em) {
+                    // hand the lanes' (slot, light) pairs over
+                    const uint32_t n = (uint32_t)__popcll(em);
+                    uint32_t e0 = 0;
+                    if (lane == 0) e0 = atomicAdd(a.exact_count, n);
+                    e0 = __builtin_amdgcn_readfirstlane(e0);
+                    if (need_exact) {   // entries beyond the capacity are only counted: the host then enlarges the list
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                        if (e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(base + lane, (uint32_t)l);
+                    }
+                }
                 if (defer) {
 #pragma unroll
                     for (int s = 0; s < SMALL_MAX; ++s)
@@ -878,7 +927,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 }
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
-                phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+                phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
             }
         }
         if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
@@ -945,6 +994,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         const float lc2 = dot(lrel, lrel);
         const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
         const f3 ldir = lrel * linv;
+        // own sphere with c > 0: inward shadow rays are decided in float64 (rt_exact.h)
+        const bool exact = active && own_id >= 0 && (flags & HF_EXACT);
+        // Shallow inward rays need no float64: the near root is resolved (t1 > 0, no blocker) whenever
+        // 4ac >= 2^-50 b^2, and c > 0 means c >= one quantum of r^2 >= 2^-54 r^2, so b^2 <= r^2 / 4 is safe: with
+        // b = 2 w.oc that is |w.oc| <= r / 4.  Steeper samples (w.oc < -0.2 r) are evaluated in float64.
+        const float inward_limit = -0.2f * own_sf.c.x;
+        const double* p64 = a.q.p64 + (size_t)(base + lane) * 3;
         float ratio;
         if (lt.point_path) {
             // ---- one ray to the light centre (ray_tracer.py:36-48), literal form (every wave computes it)
@@ -959,6 +1015,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                 else blk = box_blocks_a(sf, P, ldir, dist, own, h.nrm, flags);
                 f = blk ? f * sf.transp : f;
             }
+            if (exact && (flags & HF_CDOT_POS) && dot(ldir, P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z)) < inward_limit &&
+                rtx::own_sphere_blocks_centre(p64, a.light64 + (size_t)l * 4, a.surf64[own_id]))
+                f *= own_sf.transp;
             ratio = f;
         } else {
             // ---- per-(hit, surface) constants
@@ -990,6 +1049,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             // sphere: oc; box: outward normal.  w . ov < 0  <=>  the sample enters the body
             const f3 ov = own_sphere ? P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z) : h.nrm;
             const bool own_sph_blocks_b = own_sphere && !(flags & HF_CBATCH_POS);
+            const bool exact_b = exact && own_sphere && (flags & HF_CBATCH_POS);
             const float own_tr = own_sf.transp;
             float ob[6];
 #pragma unroll
@@ -1003,6 +1063,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const f3 up = normalize(cross(right, ldir));
             const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
             const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
+            if (wv == 0) {
+                // own sphere with c > 0 and a sample that may enter it steeply: the loop below applies the rule ("never
+                // blocks") and k_shade_exact adds the float64 correction (same predicate as in k_shade_fast)
+                const float llen = lc2 * linv;
+                const bool list = exact_b && dot(lrel, ov) - (0.5002f * lt.radius + 1e-6f) * (fabsf(dot(right, ov)) + fabsf(dot(up, ov))) <
+                                                 own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + lt.radius));
+                const unsigned long long em = __ballot(list);
+                if (em) {
+                    uint32_t e0 = 0;
+                    if (lane == 0) e0 = atomicAdd(a.exact_count, (uint32_t)__popcll(em));
+                    e0 = __builtin_amdgcn_readfirstlane(e0);
+                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                    if (list && e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(base + lane, (uint32_t)l);
+                }
+            }
             float sum = 0.f;
             for (int i = wv; i < N; i += NWV) {
                 const float cu = ((float)i * invN - 0.5f) * lt.radius;
@@ -1096,6 +1171,97 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
     }
 }
 
+// (hit, light) pairs of the fast kernel whose own sphere has to be evaluated in float64 (rt_exact.h).  The fast
+// kernel has shaded the pair with the own sphere taken as "never blocks" (the rule for c > 0); this kernel adds the
+// correction: for every sample that enters the sphere steeply and that the float64 quadratic finds blocked, the
+// light factor of the other surfaces (generic FP32 forms) times (transparency - 1).  One wave per pair, the lanes
+// share the N x N samples; most pairs have few such samples (a wide light low over the horizon of the hit) or none.
+__global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
+    const uint32_t listed = *a.exact_count;
+    const uint32_t n_items = listed < a.exact_capacity ? listed : a.exact_capacity;
+    const int N = a.fp.n_shadow;
+    const float invN = 1.0f / (float)N;
+    const double inv_n64 = (N & (N - 1)) == 0 ? 1.0 / (double)N : 0.0;   // exact reciprocal of a power of two (rt_exact.h)
+    const uint32_t lane = threadIdx.x & 63;
+    // the pairs asked for, listed or not: the host compares it with the capacity
+    if (blockIdx.x == 0 && threadIdx.x == 0 && listed) atomicAdd(&a.counters[CNT_EXACT], (unsigned long long)listed);
+    // a wave takes 2 pairs at a time, the first batch by its own index (a wave with nothing to do leaves without
+    // touching the shared counter: usually there are fewer batches than waves), the following ones from the counter
+    constexpr uint32_t BATCH = 2;
+    const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    auto next_batch = [&]() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(a.work3, BATCH);
+        return (uint32_t)__builtin_amdgcn_readfirstlane(v) + n_waves * BATCH;
+    };
+    for (uint32_t b0 = wave * BATCH; b0 < n_items; b0 = next_batch())
+    for (uint32_t it = b0; it < b0 + BATCH && it < n_items; ++it) {
+        const uint2 e = a.exact[it];
+        const uint32_t slot = __builtin_amdgcn_readfirstlane(e.x);
+        const int l = (int)__builtin_amdgcn_readfirstlane(e.y);
+        if (slot != RT_NULL_HIT) {
+            const HitRec h = load_hit(a.q, slot);
+            const f3 P = h.P;
+            const int own_id = h.own_id;
+            const SurfF own_sf = a.surf[own_id];
+            const LightF lt = a.light[l];
+            const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);
+            const float inward_limit = -0.2f * own_sf.c.x;   // see k_shade_deferred
+            const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+            const float lc2 = dot(lrel, lrel);
+            const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
+            const f3 ldir = lrel * linv;
+            const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
+            const f3 right = normalize(cross(ldir, perp));
+            const f3 up = normalize(cross(right, ldir));
+            const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
+            auto sample = [&](uint32_t s_idx, int& i, int& j, uint32_t& ub, uint32_t& vb, f3& w, float& dist) {
+                i = (int)(s_idx / (uint32_t)N); j = (int)(s_idx % (uint32_t)N);
+                rt_sample_bits(key, s_idx, ub, vb);
+                const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
+                const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
+                const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
+                const float d2 = dot(sv, sv);
+                const float dinv = __frsqrt_rn(d2);
+                w = sv * dinv;
+                dist = d2 * dinv;
+            };
+            // pass 1: does any sample enter steeply at all?
+            bool steep = false;
+            for (uint32_t s_idx = lane; s_idx < (uint32_t)(N * N); s_idx += 64u) {
+                int i, j; uint32_t ub, vb; f3 w; float dist;
+                sample(s_idx, i, j, ub, vb, w, dist);
+                steep = steep || dot(w, ov) < inward_limit;
+            }
+            if (__any(steep)) {
+                const double* light64 = a.light64 + (size_t)l * 4;
+                const rtx::OwnSphere os = rtx::own_sphere_setup(a.q.p64 + (size_t)slot * 3, light64);
+                float delta = 0.f;
+                for (uint32_t s_idx = lane; s_idx < (uint32_t)(N * N); s_idx += 64u) {
+                    int i, j; uint32_t ub, vb; f3 w; float dist;
+                    sample(s_idx, i, j, ub, vb, w, dist);
+                    if (dot(w, ov) < inward_limit &&
+                        rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
+                        delta += shadow_factor<true>(a, P, w, dist, own_id, h.nrm, h.flags, ~0ull) * (own_sf.transp - 1.f);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o);
+                if (lane == 0 && delta != 0.f) {
+                    const MatF m = a.mat[own_sf.mat];
+                    f3 c1 = F3(0.f, 0.f, 0.f), c0 = F3(0.f, 0.f, 0.f);
+                    phong_add(c1, h.nrm, ldir, h.view, m, lt, delta / (float)(N * N));   // affine in the ratio:
+                    phong_add(c0, h.nrm, ldir, h.view, m, lt, 0.f);                       // the difference is the correction
+                    const f3 color = c1 - c0;
+                    unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], (double)(h.wgt.x * color.x));
+                    unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], (double)(h.wgt.y * color.y));
+                    unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(h.wgt.z * color.z));
+                }
+            }
+        }
+    }
+}
+
 void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
     const dim3 g(blocks), b(SHADE_BLOCK);
     if (a.variant == SHADE_GENERAL || a.fp.n_surfaces > SMALL_MAX) {
@@ -1116,6 +1282,7 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
         if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<false, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_shade_deferred<false, false>), g, b, 0, s, a);
     }
+    hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -202,6 +202,7 @@ __device__ __forceinline__ HitFrame hit_frame(const SurfD& sf, d3 o, d3 d, doubl
         f.n = divs(oc, sf.d[3]);                                   // sphere.py:62-63
         if (dots(oc, oc) - sf.d[5] > 0) f.flags |= HF_CBATCH_POS;  // sphere.py:93
         if (dotb(oc, oc) - sf.d[4] > 0) f.flags |= HF_CDOT_POS;    // sphere.py:38
+        if (f.flags) f.flags |= HF_EXACT;
     } else if (sf.type == RT_SURF_PLANE) {
         f.n = D3(sf.d[0], sf.d[1], sf.d[2]);
     } else {
@@ -230,6 +231,7 @@ __device__ __forceinline__ void store_shade(const ShadeQueue& q, uint32_t slot, 
     q.r1[slot] = make_float4((float)f.n.y, (float)f.n.z, (float)view.x, (float)view.y);
     q.r2[slot] = make_float4((float)view.z, tr * om, tg * om, tb * om);
     q.r3[slot] = make_uint4(lpix, gpix, node, (uint32_t)bs | (f.flags << 24));
+    if (f.flags & HF_EXACT) { q.p64[(size_t)slot * 3 + 0] = f.P.x; q.p64[(size_t)slot * 3 + 1] = f.P.y; q.p64[(size_t)slot * 3 + 2] = f.P.z; }
 }
 
 __device__ __forceinline__ void store_debug(const HitDebug& g, uint32_t slot, uint32_t gpix, uint32_t node, int bs, bool hit, double best,

@@ -17,7 +17,7 @@ def load(text):
 
 r = runtime.Renderer(0)
 seed = int(sys.argv[1])
-text = _random_scene_text(5000 + seed)
+text = _random_scene_text(5000 + seed, int(os.environ.get('FAMILY', '0')))
 lines = text.strip().split("\n")
 lights = [i for i, l in enumerate(lines) if l.startswith("lgt")]
 setl = [i for i, l in enumerate(lines) if l.startswith("set")][0]
