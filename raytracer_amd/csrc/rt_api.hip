@@ -24,6 +24,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <array>
+#include <map>
 #include <vector>
 
 #pragma clang fp contract(off)
@@ -646,6 +648,18 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
         }
     }
     if (any_box) test_flops += 3;
+    {   // twin groups (SurfF::pad, SurfF::b.w): surfaces whose float64 records are equal
+        std::map<std::array<double, 8>, int> first;
+        for (int s = 0; s < S; ++s) {
+            std::array<double, 8> key{};
+            for (int k = 0; k < 7; ++k) key[k] = sd[s].d[k];
+            key[7] = (double)sd[s].type;
+            sf[s].pad = first.emplace(key, s).first->second;
+            sf[s].b.w = 1.f;
+        }
+        for (int s = 0; s < S; ++s) sf[sf[s].pad].b.w *= sf[s].transp;
+        for (int s = 0; s < S; ++s) sf[s].b.w = sf[sf[s].pad].b.w;
+    }
     std::vector<LightF> lights((size_t)std::max(L, 1));
     std::memset(lights.data(), 0, sizeof(LightF) * lights.size());
     double rays_per_hit = 0;

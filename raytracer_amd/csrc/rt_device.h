@@ -26,14 +26,17 @@ struct SurfD {
 //   sphere: a = (cx, cy, cz, r*r)
 //   plane : a = (nx, ny, nz, offset)
 //   box   : a = (minx, miny, minz, -), b = (maxx, maxy, maxz, -)
+// Surfaces with identical geometry ("twins": a line of the scene file repeated) form a group; a shadow ray that
+// starts on one of them starts on all, so the own-surface rules apply to the whole group.
+//   pad = index of the group's first surface, b.w = product of the group's transparencies
 struct __attribute__((aligned(16))) SurfF {
     float4 a;
-    float4 b;       // box only
+    float4 b;       // box: max corner; .w (all types): see above
     float4 c;       // sphere: (radius, -, -, -); box: bounding sphere (centre, radius)
     int32_t type;
     float transp;   // transparency of the surface's material (shadow attenuation)
     int32_t mat;
-    int32_t pad;
+    int32_t pad;    // first surface of its twin group (itself when it has no twin)
 };
 
 // ---- uniform grid over the bounded surfaces (spheres, boxes), built on upload for large scenes ----

@@ -229,30 +229,33 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
                                                unsigned long long reach_mask) {
     const SceneGrid& g = a.grid;
     float f = 1.f;
+    // surfaces with the same geometry as the hit's own one (SurfF::pad names the first of them) start on the ray
+    // origin just like it and follow the same rule
+    const int own_grp = own_id >= 0 ? a.surf[own_id].pad : -1;
     if (!g.cell_start) {
         const int S = a.fp.n_surfaces;
         if (S <= 64) {   // only the surfaces some lane of the wave can reach from this light (wave-uniform mask)
             for (unsigned long long m = reach_mask & (S == 64 ? ~0ull : (1ull << S) - 1ull); m; m &= m - 1ull) {
                 const int s = (int)__builtin_ctzll(m);
                 const SurfF sf = a.surf[s];
-                f = surface_blocks<BATCH>(sf, P, w, dist, s == own_id, nrm, flags) ? f * sf.transp : f;
+                f = surface_blocks<BATCH>(sf, P, w, dist, sf.pad == own_grp, nrm, flags) ? f * sf.transp : f;
             }
             return f;
         }
         for (int s = 0; s < S; ++s) {
             const SurfF sf = a.surf[s];
-            f = surface_blocks<BATCH>(sf, P, w, dist, s == own_id, nrm, flags) ? f * sf.transp : f;
+            f = surface_blocks<BATCH>(sf, P, w, dist, sf.pad == own_grp, nrm, flags) ? f * sf.transp : f;
         }
         return f;
     }
     if (own_id >= 0) {  // the hit's own surface, by rule, once
         const SurfF sf = a.surf[own_id];
-        f = surface_blocks<BATCH>(sf, P, w, dist, true, nrm, flags) ? f * sf.transp : f;
+        f = surface_blocks<BATCH>(sf, P, w, dist, true, nrm, flags) ? f * sf.b.w : f;   // b.w: product over its twins
     }
     for (int k = 0; k < g.n_global; ++k) {
         const int j = (int)g.global_items[k];
-        if (j == own_id) continue;
         const SurfF sf = a.surf[j];
+        if (sf.pad == own_grp) continue;
         f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
     }
     if (f == 0.f) return f;
@@ -291,11 +294,11 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
         const uint32_t k0 = g.cell_start[c], k1 = g.cell_start[c + 1];
         for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t j = g.items[k];
-            if ((int)j == own_id) continue;
             bool seen = false;
             for (uint32_t q = p0; q < p1; ++q) seen = seen || g.items[q] == j;
             if (seen) continue;
             const SurfF sf = a.surf[j];
+            if (sf.pad == own_grp) continue;
             f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
         }
         if (f == 0.f) return f;
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags, ~0ull);
                 if (exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
                     rtx::own_sphere_blocks_centre(p64, a.light64 + (size_t)l * 4, a.surf64[own_id]))
-                    ratio *= own_sf.transp;
+                    ratio *= own_sf.b.w;
             } else {
                 // ---- light basis (light.py:24-30) and the N x N grid (light.py:51-63)
                 const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         float f = shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
                         if (exact_b && dot(w, ov) < inward_limit &&
                             rtx::own_sphere_blocks_sample(os, a.light64 + (size_t)l * 4, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
-                            f *= own_sf.transp;
+                            f *= own_sf.b.w;
                         sum += f;
                     }
                 }
@@ -722,8 +725,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 for (int j = 0; j < SMALL_MAX; ++j) {
                     A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
                     if (j < S) {
-                        const bool own = own_valid && j == h.own_id;
                         const SurfF sf = a.surf[j];
+                        const bool own = own_valid && sf.pad == own_sf.pad;   // the own surface or a twin of it
                         if (STYPE(j) == RT_SURF_SPHERE) {
                             const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
                             const float c = dot(oc, oc) - sf.a.w;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                                     if (!ALL_OPAQUE && t < SMALL_MAX) trd[e] = a.surf[t < SMALL_MAX ? t : 0].transp;
                                 }
                             }
-                            if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.transp;
+                            if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.b.w;
                         }
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
                         const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
@@ -1008,7 +1011,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             float f = 1.f;
             for (int s = 0; s < S; ++s) {
                 const SurfF sf = a.surf[s];
-                const bool own = s == own_id;
+                const bool own = own_id >= 0 && sf.pad == own_sf.pad;
                 bool blk;
                 if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
                 else if (sf.type == RT_SURF_PLANE) blk = plane_blocks_a(sf, P, ldir, dist, own);
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             }
             if (exact && (flags & HF_CDOT_POS) && dot(ldir, P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z)) < inward_limit &&
                 rtx::own_sphere_blocks_centre(p64, a.light64 + (size_t)l * 4, a.surf64[own_id]))
-                f *= own_sf.transp;
+                f *= own_sf.b.w;
             ratio = f;
         } else {
             // ---- per-(hit, surface) constants
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                 for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
                 if (j < S) {
                     const SurfF sf = a.surf[j];
-                    const bool own = j == own_id;
+                    const bool own = own_id >= 0 && sf.pad == own_sf.pad;
                     if (STYPE(j) == RT_SURF_SPHERE) {
                         const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
                         g[j][0] = oc.x; g[j][1] = oc.y; g[j][2] = oc.z;
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const f3 ov = own_sphere ? P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z) : h.nrm;
             const bool own_sph_blocks_b = own_sphere && !(flags & HF_CBATCH_POS);
             const bool exact_b = exact && own_sphere && (flags & HF_CBATCH_POS);
-            const float own_tr = own_sf.transp;
+            const float own_tr = own_sf.b.w;   // product over the own surface and its twins
             float ob[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) ob[c] = 0.f;
@@ -1243,7 +1246,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
                     sample(s_idx, i, j, ub, vb, w, dist);
                     if (dot(w, ov) < inward_limit &&
                         rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
-                        delta += shadow_factor<true>(a, P, w, dist, own_id, h.nrm, h.flags, ~0ull) * (own_sf.transp - 1.f);
+                        delta += shadow_factor<true>(a, P, w, dist, own_id, h.nrm, h.flags, ~0ull) * (own_sf.b.w - 1.f);
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o);

@@ -657,6 +657,27 @@ def test_far_side_of_a_glass_ball_is_decided_in_float64(renderer, oracle, tmp_pa
     small.close(); fresh.close()
 
 
+def test_repeated_surface_lines_share_the_own_surface_rule(renderer, oracle, tmp_path):
+    """A sphere, a box and a plane each listed twice (with different transparent materials): a shadow ray that starts
+    on one starts on its twin too, and the reference's float64 arithmetic treats both alike; so does the library
+    (twin groups), in the register-resident kernels and in the any-size one."""
+    text = ("cam 0.2 1.3 5.5  0.3 0.8 0  0 1 0  1.3 1.5\nset 0.1 0.5 0.3 4 3\n"
+            "mtl 0.2 0.6 0.3  0.4 0.3 0.2  0 0 0  10 0.5\nmtl 0.9 0.3 0.5  0.8 0.5 0.5  0 0 0  2 0.25\n"
+            "mtl 0.5 0.5 0.5  1 1 1  0.3 0.3 0.3  50 0\n"
+            "pln 0 1 0 -0.3 3\npln 0 1 0 -0.3 1\nsph -0.6 1.1 0.1 0.75 1\nsph -0.6 1.1 0.1 0.75 2\n"
+            "box 1.2 0.6 -0.8 1.1 2\nbox 1.2 0.6 -0.8 1.1 1\n"
+            "lgt -3.5 3.6 0.6  1 0.6 0.7  1 1 3\nlgt 2 4 3  0.5 0.7 1  0.5 0.8 1\n")
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    renderer.set_scene(sc)
+    w, h = 96, 64
+    ref, cnt = oracle.render_frame(sc, w, h, seed=9, threads=THREADS)
+    for flags in (0, 1):
+        _, u8, st = renderer.render_rows(w, h, seed=9, flags=flags)
+        assert counters_of(st) == cnt
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] == 0, (flags, m)
+
+
 def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
     """Hit points tens of thousands of units away (a level camera over an infinite plane): their shadow rays
     graze the objects near the origin from afar, where the literal FP32 sphere quadratic is pure cancellation."""
