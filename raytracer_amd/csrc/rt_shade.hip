@@ -1070,8 +1070,17 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                 // own sphere with c > 0 and a sample that may enter it steeply: the loop below applies the rule ("never
                 // blocks") and k_shade_exact adds the float64 correction (same predicate as in k_shade_fast)
                 const float llen = lc2 * linv;
-                const bool list = exact_b && dot(lrel, ov) - (0.5002f * lt.radius + 1e-6f) * (fabsf(dot(right, ov)) + fabsf(dot(up, ov))) <
-                                                 own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + lt.radius));
+                bool list = exact_b && dot(lrel, ov) - (0.5002f * lt.radius + 1e-6f) * (fabsf(dot(right, ov)) + fabsf(dot(up, ov))) <
+                                           own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + lt.radius));
+                if (list) {   // ... and only if the pair can show: front-lit, or a specular term above exact_min
+                    const float ndl0 = dot(h.nrm, ldir);
+                    if (!(ndl0 > 0.f)) {
+                        const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
+                        const float sp = rv0 > 0.f ? pow_pos(rv0, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+                        const float cmax = fmaxf(fmaxf(m.ks[0] * lt.col[0] * h.wgt.x, m.ks[1] * lt.col[1] * h.wgt.y), m.ks[2] * lt.col[2] * h.wgt.z);
+                        list = sp * lt.spec * lt.shadow * cmax > a.exact_min;
+                    }
+                }
                 const unsigned long long em = __ballot(list);
                 if (em) {
                     uint32_t e0 = 0;
