@@ -678,6 +678,27 @@ def test_repeated_surface_lines_share_the_own_surface_rule(renderer, oracle, tmp
         assert m["pixels_beyond_1lsb"] == 0, (flags, m)
 
 
+@pytest.mark.parametrize("n,rec,lights,w,h", [(17, 4, 2, 64, 40), (7, 31, 1, 48, 32), (300, 2, 1, 16, 10), (3, 3, 12, 64, 40),
+                                              (255, 2, 1, 16, 10), (1, 10, 3, 96, 64)])
+def test_unusual_parameters(renderer, oracle, tmp_path, n, rec, lights, w, h):
+    """Shadow grids that are not a power of two, beyond the register-resident kernel's 255, the recursion limit of 31
+    with mirrors facing each other, a dozen lights, single-ray shadows: counters exact, image within 1 LSB everywhere."""
+    rng = np.random.default_rng(5)
+    lgt = "".join(f"lgt {rng.uniform(-4, 4):.3f} {rng.uniform(2, 5):.3f} {rng.uniform(-2, 5):.3f}  1 0.9 0.8  1 "
+                  f"{rng.uniform(0.3, 1):.2f} {rng.uniform(0.3, 2):.2f}\n" for _ in range(lights))
+    text = (f"cam 0 1.2 5  0 0.8 0  0 1 0  1.4 1.6\nset 0.2 0.3 0.5 {n} {rec}\n"
+            "mtl 0.6 0.7 0.8  1 1 1  0.9 0.9 0.9  8 0.5\nmtl 0.7 0.6 0.4  0.5 0.5 0.5  0.8 0.8 0.8  30 0\n"
+            "pln 0 1 0 -0.5 2\npln 0 0 1 -4 2\nsph 0.4 1.0 0.5 1.1 1\nsph -1.8 0.7 -1 0.6 2\nbox 1.5 0.2 1.5 1.0 2\n" + lgt)
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=2, threads=THREADS)
+    for flags in (0, 1):
+        _, u8, st = renderer.render_rows(w, h, seed=2, flags=flags)
+        assert counters_of(st) == cnt
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] == 0, (flags, m)
+
+
 def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
     """Hit points tens of thousands of units away (a level camera over an infinite plane): their shadow rays
     graze the objects near the origin from afar, where the literal FP32 sphere quadratic is pure cancellation."""
