@@ -316,7 +316,6 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
     const int L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
-    const double inv_n64 = (N & (N - 1)) == 0 ? 1.0 / (double)N : 0.0;   // exact reciprocal of a power of two (rt_exact.h)
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
@@ -393,9 +392,30 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         if (__any(lit && (reach || s == own_id))) reach_mask |= 1ull << s;
                     }
                 }
-                const bool exact_b = exact && (flags & HF_CBATCH_POS) && reach_mask != 0ull;
-                rtx::OwnSphere os;
-                if (exact_b) os = rtx::own_sphere_setup(p64, a.light64 + (size_t)l * 4);
+                {   // own sphere with c > 0 and a sample that may enter it steeply: the loop below applies the rule ("never
+                    // blocks") and k_shade_exact adds the float64 correction (same predicate as in k_shade_fast)
+                    const float llen = lc2 * linv;
+                    bool list = exact && (flags & HF_CBATCH_POS) && reach_mask != 0ull &&
+                                dot(lrel, ov) - (0.5002f * lt.radius + 1e-6f) * (fabsf(dot(right, ov)) + fabsf(dot(up, ov))) <
+                                    own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + lt.radius));
+                    if (list) {
+                        const float ndl0 = dot(nrm, ldir);
+                        if (!(ndl0 > 0.f)) {
+                            const float rv0 = 2.f * ndl0 * dot(nrm, view) - dot(ldir, view);
+                            const float sp = rv0 > 0.f ? pow_pos(rv0, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+                            const float cmax = fmaxf(fmaxf(m.ks[0] * lt.col[0] * hr.wgt.x, m.ks[1] * lt.col[1] * hr.wgt.y), m.ks[2] * lt.col[2] * hr.wgt.z);
+                            list = sp * lt.spec * lt.shadow * cmax > a.exact_min;
+                        }
+                    }
+                    const unsigned long long em = __ballot(list);
+                    if (em) {
+                        uint32_t e0 = 0;
+                        if (lane == 0) e0 = atomicAdd(a.exact_count, (uint32_t)__popcll(em));
+                        e0 = __builtin_amdgcn_readfirstlane(e0);
+                        const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                        if (list && e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(base + lane, (uint32_t)l);
+                    }
+                }
                 float sum = 0.f;
                 uint32_t s_idx = 0;
                 for (int i = 0; i < N && reach_mask; ++i) {
@@ -409,11 +429,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         const float dinv = __frsqrt_rn(d2);
                         const f3 w = sv * dinv;
                         const float dist = d2 * dinv;
-                        float f = shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
-                        if (exact_b && dot(w, ov) < inward_limit &&
-                            rtx::own_sphere_blocks_sample(os, a.light64 + (size_t)l * 4, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
-                            f *= own_sf.b.w;
-                        sum += f;
+                        sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
                     }
                 }
                 ratio = reach_mask ? sum * inv_n2 : 1.f;
@@ -1278,6 +1294,7 @@ void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
     const dim3 g(blocks), b(SHADE_BLOCK);
     if (a.variant == SHADE_GENERAL || a.fp.n_surfaces > SMALL_MAX) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
+        hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
         return;
     }
     if (a.has_box) {
