@@ -459,7 +459,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 
 
 // =======================================================================================
-// Small scenes (<= SMALL_MAX surfaces): two kernels.
+// Small scenes (<= 16 surfaces; template parameter SM = 8 or 16 surface slots): two kernels.
 //
 // k_shade_fast      classifies, per (hit, light), every surface against the light's sample
 //                   square (all samples lie within rho = radius/sqrt(2) of the light centre L):
@@ -495,8 +495,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 // Light contributions are additive, so the two kernels simply add into the same pixel
 // accumulators.
 // =======================================================================================
-#define SMALL_MAX 8
-#define NSLOT (SMALL_MAX + 1)  // + one slot for the hit's own sphere
+#define SMALL_MAX 8            // surfaces the kernels handle at full occupancy (SM = 8); SM = 16 serves 9..16
 #define KMAX 8                 // linear tests the compact sample loop keeps in registers
 #define NBMAX 3                // boxes it can test beside them
 #define PLANE_SCALE 1152921504606846976.0f  // 2^60
@@ -655,8 +654,9 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     return ALL_OPAQUE ? (float)open_samples : sum;
 }
 
-template <bool ALL_OPAQUE, bool HAS_BOX>
-__global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(ShadeArgs a) {
+template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
+__global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k_shade_fast(ShadeArgs a) {
+    constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
@@ -666,11 +666,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
 
     // wave-uniform: 4 type bits per surface in one word
-    uint32_t tword = 0;
+    unsigned long long tword = 0;
 #pragma unroll
-    for (int j = 0; j < SMALL_MAX; ++j) tword |= (j < S ? (uint32_t)a.surf[j].type : 0xFu) << (4 * j);
-    tword = __builtin_amdgcn_readfirstlane(tword);
-#define STYPE(j) ((tword >> (4 * (j))) & 0xFu)
+    for (int j = 0; j < SM; ++j) tword |= (unsigned long long)(j < S ? (uint32_t)a.surf[j].type : 0xFu) << (4 * j);
+    tword = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tword) |
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
+#define STYPE(j) ((uint32_t)(tword >> (4 * (j))) & 0xFu)
 
     // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
     // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
         for (int l = 0; l < L; ++l) {
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
-            uint32_t defer_mask = defer ? 0xFFu : 0u;  // surfaces the generic loop has to test for this (wave, light)
+            uint32_t defer_mask = defer ? (1u << SM) - 1u : 0u;  // surfaces the generic loop has to test for this (wave, light)
             bool need_exact = false;                   // this lane's pair also goes to k_shade_exact (correction)
             float ratio = 1.f;
             const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
@@ -734,11 +735,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 const float ndl0 = dot(h.nrm, ldir);
                 const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
-                float A[NSLOT], B[NSLOT], C[NSLOT];
+                float A[(SM + 1)], B[(SM + 1)], C[(SM + 1)];
                 bool gen = false;
                 uint32_t lin = 0, reach_bits = 0, box_bits = 0;
 #pragma unroll
-                for (int j = 0; j < SMALL_MAX; ++j) {
+                for (int j = 0; j < SM; ++j) {
                     A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
                     if (j < S) {
                         const SurfF sf = a.surf[j];
@@ -804,7 +805,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                         }
                     }
                 }
-                A[SMALL_MAX] = -INFINITY; B[SMALL_MAX] = 0.f; C[SMALL_MAX] = 0.f;
+                A[SM] = -INFINITY; B[SM] = 0.f; C[SM] = 0.f;
                 // own sphere with c > 0 and a sample that may enter it steeply: k_shade_exact decides those samples in float64.
                 // Such a light lies behind the tangent plane (no diffuse term); when its specular term is below 1e-4 of
                 // full scale (0.03 LSB) for every channel, whatever the shadow ratio, the float64 answer cannot show.
@@ -827,20 +828,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                     if (dl - rho * r * 1.0002f < 0.f) {  // some sample may enter the own sphere
                         if (llen - rho > 2.0002f * r) {
                             const float k = -2.0e6f;      // far root -2 w.oc > 1e-6  <=>  -sv.oc * 2e6 > len
-                            A[SMALL_MAX] = dl * k; B[SMALL_MAX] = dot(right, ov) * k; C[SMALL_MAX] = dot(up, ov) * k;
-                            lin |= 1u << SMALL_MAX;
+                            A[SM] = dl * k; B[SM] = dot(right, ov) * k; C[SM] = dot(up, ov) * k;
+                            lin |= 1u << SM;
                         } else gen = true;
                     }
                 }
                 uint32_t cand = 0;
 #pragma unroll
-                for (int s = 0; s < NSLOT; ++s)
+                for (int s = 0; s < (SM + 1); ++s)
                     if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
                 const int k = __popc(cand);
                 uint32_t bcand = 0;
                 if (HAS_BOX) {
 #pragma unroll
-                    for (int s = 0; s < SMALL_MAX; ++s)
+                    for (int s = 0; s < SM; ++s)
                         if (STYPE(s) == RT_SURF_BOX && __ballot((box_bits >> s) & 1u)) bcand |= 1u << s;
                 }
                 const int nb = __popc(bcand);
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                 }
                 if (defer) {
 #pragma unroll
-                    for (int s = 0; s < SMALL_MAX; ++s)
+                    for (int s = 0; s < SM; ++s)
                         if (__ballot((reach_bits >> s) & 1u)) defer_mask |= 1u << s;
                 }
                 if (!defer) {
@@ -875,13 +876,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
                             rem &= rem - 1u;
                             Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
 #pragma unroll
-                            for (int t = 0; t < NSLOT; ++t) {
+                            for (int t = 0; t < (SM + 1); ++t) {
                                 if (sl == t) {
                                     Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t];
-                                    if (!ALL_OPAQUE && t < SMALL_MAX) trd[e] = a.surf[t < SMALL_MAX ? t : 0].transp;
+                                    if (!ALL_OPAQUE && t < SM) trd[e] = a.surf[t < SM ? t : 0].transp;
                                 }
                             }
-                            if (!ALL_OPAQUE && sl == SMALL_MAX) trd[e] = own_sf.b.w;
+                            if (!ALL_OPAQUE && sl == SM) trd[e] = own_sf.b.w;
                         }
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
                         const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
@@ -942,7 +943,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
             if (defer) {
                 if (lane == 0) {
                     const uint32_t slot = atomicAdd(a.deferred_count, 1u);
-                    a.deferred[slot] = make_uint2(base, (uint32_t)l | (defer_mask << 24));
+                    a.deferred[slot] = make_uint2(base, (uint32_t)l | (defer_mask << MASK_SHIFT));
                 }
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
@@ -963,8 +964,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, HAS_BOX ? 3 : 4) void k_shade_fast(Sha
     }
 }
 
-template <bool HAS_BOX, bool ALL_OPAQUE>
+template <bool HAS_BOX, bool ALL_OPAQUE, int SM>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
+    constexpr uint32_t MASK_SHIFT = 32 - SM;
     const uint32_t count = queue_slots(a.q);
     const uint32_t n_items = *a.deferred_count;
     const int S = a.fp.n_surfaces, N = a.fp.n_shadow;
@@ -972,16 +974,17 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
 
-    uint32_t tword = 0;
-    float str[SMALL_MAX];
+    unsigned long long tword = 0;
+    float str[SM];
 #pragma unroll
-    for (int j = 0; j < SMALL_MAX; ++j) {
+    for (int j = 0; j < SM; ++j) {
         str[j] = 0.f;
         uint32_t ty = 0xFu;
         if (j < S) { ty = (uint32_t)a.surf[j].type; if (!ALL_OPAQUE) str[j] = a.surf[j].transp; }
-        tword |= ty << (4 * j);
+        tword |= (unsigned long long)ty << (4 * j);
     }
-    tword = __builtin_amdgcn_readfirstlane(tword);
+    tword = (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)tword) |
+            ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
 
     // One item per WORKGROUP: its four waves hold the same 64 hits and split the sample rows
     // (wave w takes rows w, w+4, ...); partial sums meet in LDS.  Items are few and long, so the
@@ -998,8 +1001,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         if (item >= n_items) break;
         const uint2 it = a.deferred[item];
         const uint32_t base = __builtin_amdgcn_readfirstlane(it.x);
-        const int l = (int)(__builtin_amdgcn_readfirstlane(it.y) & 0xFFFFFFu);
-        const uint32_t smask = __builtin_amdgcn_readfirstlane(it.y) >> 24;  // surfaces in reach of some lane
+        const int l = (int)(__builtin_amdgcn_readfirstlane(it.y) & ((1u << MASK_SHIFT) - 1u));
+        const uint32_t smask = __builtin_amdgcn_readfirstlane(it.y) >> MASK_SHIFT;  // surfaces in reach of some lane
         HitRec h;
         bool active;
         if (!load_chunk(a.q, base, count, lane, h, active)) continue;  // (same chunk in all four waves)
@@ -1040,9 +1043,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             ratio = f;
         } else {
             // ---- per-(hit, surface) constants
-            float g[SMALL_MAX][HAS_BOX ? 6 : 5];
+            float g[SM][HAS_BOX ? 6 : 5];
 #pragma unroll
-            for (int j = 0; j < SMALL_MAX; ++j) {
+            for (int j = 0; j < SM; ++j) {
 #pragma unroll
                 for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
                 if (j < S) {
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                     bool any = false;
                     float f = 1.f;
 #pragma unroll
-                    for (int s = 0; s < SMALL_MAX; ++s) {
+                    for (int s = 0; s < SM; ++s) {
                         if (s < S && ((smask >> s) & 1u)) {
                             bool blk;
                             if (STYPE(s) == RT_SURF_SPHERE) {
@@ -1290,26 +1293,36 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     }
 }
 
+template <int SM>
+static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s) {
+    if (a.has_box) {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, true, SM>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_fast<false, true, SM>), g, b, 0, s, a);
+    } else {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, false, SM>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_fast<false, false, SM>), g, b, 0, s, a);
+    }
+    if (a.has_box) {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<true, true, SM>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_deferred<true, false, SM>), g, b, 0, s, a);
+    } else {
+        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<false, true, SM>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_shade_deferred<false, false, SM>), g, b, 0, s, a);
+    }
+}
+
+// Scenes of up to 8 surfaces use the register-resident kernels at full occupancy, 9..16 surfaces the same kernels
+// with twice the per-surface registers (two waves per SIMD; a deferred item then has 16 bits for the light), larger
+// scenes the any-size kernel.
 void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
     const dim3 g(blocks), b(SHADE_BLOCK);
-    if (a.variant == SHADE_GENERAL || a.fp.n_surfaces > SMALL_MAX) {
+    const int S = a.fp.n_surfaces;
+    if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
-        hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
-        return;
-    }
-    if (a.has_box) {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_fast<false, true>), g, b, 0, s, a);
+    } else if (S > SMALL_MAX) {
+        launch_small<16>(a, g, b, s);
     } else {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, false>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_fast<false, false>), g, b, 0, s, a);
-    }
-    if (a.has_box) {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<true, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_deferred<true, false>), g, b, 0, s, a);
-    } else {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<false, true>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_deferred<false, false>), g, b, 0, s, a);
+        launch_small<SMALL_MAX>(a, g, b, s);
     }
     hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
 }
