@@ -699,6 +699,25 @@ def test_unusual_parameters(renderer, oracle, tmp_path, n, rec, lights, w, h):
         assert m["pixels_beyond_1lsb"] == 0, (flags, m)
 
 
+def test_twelve_surfaces_use_the_wide_register_resident_kernels(renderer, oracle, tmp_path):
+    """9..16 surfaces: the register-resident kernels in their 16-slot instantiation (classified, brute force) and the
+    any-size kernel give the oracle's image and counters."""
+    sc = R.parse_scene_file(write_scene(tmp_path, _crowded_scene_text(8, 2, seed=3).replace("set 0.3 0.4 0.6 2 3", "set 0.3 0.4 0.6 4 3")))
+    assert len(sc.surfaces) == 12
+    w, h = 128, 72
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=2, threads=THREADS)
+    classes = {}
+    for flags in (0, 2, 1):
+        _, u8, st = renderer.render_rows(w, h, seed=2, flags=flags)
+        assert counters_of(st) == cnt
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] == 0, (flags, m)
+        classes[flags] = st["wave_light"]
+    assert sum(classes[0][:5]) > 0 and sum(classes[1][:7]) == 0     # classified by the fast kernel / not at all
+    assert sum(classes[2][:5]) == 0 and classes[2][5] > 0           # brute force: every pair through the generic loop
+
+
 def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
     """Hit points tens of thousands of units away (a level camera over an infinite plane): their shadow rays
     graze the objects near the origin from afar, where the literal FP32 sphere quadratic is pure cancellation."""
