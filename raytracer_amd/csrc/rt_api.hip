@@ -66,6 +66,7 @@ struct rt_handle {
     MatF* d_mat = nullptr;
     LightF* d_light = nullptr;
     double* d_light64 = nullptr;         // float64 position xyz + radius per light (exact own-sphere evaluation)
+    unsigned long long* d_special = nullptr;  // per light: surfaces its centre lies on (ShadeArgs::special); null if none
     int has_box = 0, all_opaque = 1;
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
@@ -273,6 +274,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     fp.seed_key = rt_seed_key(p->seed);
     fp.bg[0] = h->bg[0]; fp.bg[1] = h->bg[1]; fp.bg[2] = h->bg[2];
     fp.row_y = h->d_row_y;
+    fp.all_p64 = h->d_special ? 1 : 0;
 
     HIP_TRY(h, hipEventRecord(ev[0], st));
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
@@ -310,6 +312,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
         sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
         sa.exact_min = h->exact_min;
+        sa.special = h->d_special;
         sa.exact = h->d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->exact_capacity; sa.work3 = h->d_qcounts + 47;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
@@ -565,7 +568,7 @@ void rt_destroy(rt_handle* h) {
         if (e.counters) (void)hipHostFree(e.counters);
     }
     free_frame_buffers(h);
-    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_counters,
+    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_special, (void*)h->d_counters,
                     (void*)h->stack_mem, (void*)h->d_grid_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
@@ -689,7 +692,8 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     cam.up[0] = up.x; cam.up[1] = up.y; cam.up[2] = up.z;
     cam.sdist = d->cam_screen_dist; cam.swidth = d->cam_screen_width;
 
-    for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light, (void**)&h->d_light64}) {
+    for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light, (void**)&h->d_light64,
+                     (void**)&h->d_special}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -706,6 +710,40 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_light64, light64.data(), sizeof(double) * light64.size(), hipMemcpyHostToDevice));
     int rc = build_grid(h, sd, S);
     if (rc != RT_OK) return rc;
+    // lights whose centre lies on a surface (ShadeArgs::special); scenes without a grid and of up to 64 surfaces
+    if (!h->grid.cell_start && S <= 64) {
+        std::vector<unsigned long long> special((size_t)std::max(L, 1), 0ull);
+        bool any = false;
+        for (int l = 0; l < L; ++l) {
+            const double* q = d->light_param;
+            const double p[3] = {q[0 * L + l], q[1 * L + l], q[2 * L + l]};
+            const double tol = 1e-3 * (1.0 + std::max(std::fabs(p[0]), std::max(std::fabs(p[1]), std::fabs(p[2]))));
+            for (int s2 = 0; s2 < S; ++s2) {
+                const SurfD& a = sd[s2];
+                double dist;
+                if (a.type == RT_SURF_SPHERE) {
+                    const double dx = p[0] - a.d[0], dy = p[1] - a.d[1], dz = p[2] - a.d[2];
+                    dist = std::fabs(std::sqrt(dx * dx + dy * dy + dz * dz) - std::fabs(a.d[3]));
+                } else if (a.type == RT_SURF_PLANE) {
+                    dist = std::fabs(p[0] * a.d[0] + p[1] * a.d[1] + p[2] * a.d[2] - a.d[3]);
+                } else {
+                    double out2 = 0, in_min = INFINITY;   // outside: distance to the box; inside: to the nearest face
+                    for (int k = 0; k < 3; ++k) {
+                        const double lo = std::min(a.d[k], a.d[3 + k]), hi = std::max(a.d[k], a.d[3 + k]);
+                        const double o = std::max(std::max(lo - p[k], p[k] - hi), 0.0);
+                        out2 += o * o;
+                        in_min = std::min(in_min, std::min(std::fabs(p[k] - lo), std::fabs(hi - p[k])));
+                    }
+                    dist = out2 > 0 ? std::sqrt(out2) : in_min;
+                }
+                if (dist <= tol) { special[l] |= 1ull << s2; any = true; }
+            }
+        }
+        if (any) {
+            HIP_TRY(h, hipMalloc(&h->d_special, sizeof(unsigned long long) * special.size()));
+            HIP_TRY(h, hipMemcpy(h->d_special, special.data(), sizeof(unsigned long long) * special.size(), hipMemcpyHostToDevice));
+        }
+    }
     h->S = S; h->M = M; h->L = L; h->N = d->n_shadow; h->R = d->max_rec;
     for (int c = 0; c < 3; ++c) h->bg[c] = (float)d->background[c];
     h->cam = cam;

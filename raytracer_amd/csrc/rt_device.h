@@ -98,6 +98,7 @@ struct RayQueue {
 // lies outside the band holds RT_NULL_HIT in r3.w.  Hits of deeper rays are appended from `base` on;
 // *count counts only those.
 #define RT_NULL_HIT 0xFFFFFFFFu
+#define RT_PAIR_FULL 0x80000000u   // exact-list entry: shade the whole pair (light word without this bit = light index)
 struct ShadeQueue {
     float4 *r0;   // hit point xyz, normal x
     float4 *r1;   // normal yz (stored outward normal), view xy (direction towards the ray origin)
@@ -136,6 +137,7 @@ struct FrameParams {
     uint32_t seed_key;       // mix32(seed + GOLDEN), the per-frame part of the jitter key
     float bg[3];
     const int32_t* row_y;    // image row of each band row
+    int32_t all_p64;         // 1: every shaded hit carries its float64 hit point (scene with a light lying on a surface)
 };
 
 // ---- jitter stream (contract: oracle/jitter.py) ----------------------------------
@@ -192,6 +194,11 @@ struct ShadeArgs {
     uint32_t exact_capacity;
     uint32_t* work3;     // shared work counter of k_shade_exact
     float exact_min;     // a back-lit pair goes to k_shade_exact only if its specular term can exceed this (full scale = 1)
+    // Lights whose centre lies on (within 1e-3 of) a surface: bit s of special[l] names the surface (null: the scene has
+    // none; scenes of up to 64 surfaces only).  A shadow ray towards such a light meets that surface at t = dist up to
+    // rounding, and the reference decides t < dist by the last bit of its float64 arithmetic: every pair with such a
+    // light is shaded by k_shade_exact, with those surfaces tested in float64 (list entries with RT_PAIR_FULL set).
+    const unsigned long long* special;
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;

@@ -104,6 +104,109 @@ __device__ __forceinline__ bool own_sphere_blocks_centre(const double* p64, cons
     return RT_EPS < t && t < dist;
 }
 
+// ---- any surface, float64, for lights that lie on a surface (ShadeArgs::special) ------------------------------
+
+// direction and length of the shadow ray of sample (i, j), as the reference forms them (light.py:51-63, ray_tracer.py:56-59)
+__device__ __forceinline__ void sample_ray(const OwnSphere& o, const double* light, int N, double inv_n, int i, int j,
+                                           uint32_t ub, uint32_t vb, e3& d, double& dist) {
+    const double un = (double)i + (double)ub * (1.0 / 65536.0), vn = (double)j + (double)vb * (1.0 / 65536.0);
+    double u = inv_n != 0.0 ? un * inv_n : un / (double)N;
+    double v = inv_n != 0.0 ? vn * inv_n : vn / (double)N;
+    u = u - 0.5; v = v - 0.5;
+    const double radius = light[3];
+    const e3 off = add(scl(o.right, u * radius), scl(o.up, v * radius));
+    const e3 smp = add(E3(light[0], light[1], light[2]), off);
+    const e3 rd = sub(smp, o.P);
+    dist = sqrt(dots(rd, rd));
+    d = divs(rd, dist);
+}
+
+__device__ __forceinline__ double comp(e3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// intersect_batch of the three surface kinds for one ray: t, or +inf (sphere.py:67-125, infinite_plane.py:46-81,
+// cube.py:101-173)
+__device__ __forceinline__ double batch_t(const SurfD& s, e3 o, e3 d) {
+    if (s.type == RT_SURF_SPHERE) {
+        const e3 oc = sub(o, E3(s.d[0], s.d[1], s.d[2]));
+        const double a = dots(d, d);
+        const double b = 2.0 * dots(d, oc);
+        const double c = dots(oc, oc) - s.d[5];
+        const double disc = b * b - 4 * a * c;
+        if (!(disc >= 0)) return INFINITY;
+        const double sq = sqrt(disc);
+        const double t1 = (-b - sq) / (2.0 * a);
+        const double t2 = (-b + sq) / (2.0 * a);
+        const double tn = t1 > 0 ? t1 : t2;
+        return tn > RT_EPS ? tn : INFINITY;
+    }
+    if (s.type == RT_SURF_PLANE) {
+        const e3 n = E3(s.d[0], s.d[1], s.d[2]);
+        const double denom = dots(d, n);
+        const double odn = dots(o, n);
+        const double t = fabs(denom) >= RT_EPS ? (s.d[3] - odn) / denom : INFINITY;
+        return t > RT_EPS ? t : INFINITY;
+    }
+    double t_near = -INFINITY, t_far = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double da = comp(d, a), oa = comp(o, a), lo = s.d[a], hi = s.d[3 + a];
+        if (fabs(da) < RT_EPS) {
+            if (oa < lo || oa > hi) t_far = -INFINITY;
+        } else {
+            const double inv = 1.0 / da;
+            const double t1 = (lo - oa) * inv, t2 = (hi - oa) * inv;
+            t_near = fmax(t_near, fmin(t1, t2));
+            t_far = fmin(t_far, fmax(t1, t2));
+        }
+    }
+    if (t_near > t_far || t_far < 0) return INFINITY;
+    return t_near > RT_EPS ? t_near : (t_far > RT_EPS ? t_far : INFINITY);
+}
+
+// the scalar intersect of the three kinds (sphere.py:33-59, infinite_plane.py:31-44, cube.py:36-86): hit and t
+__device__ __forceinline__ bool scalar_t(const SurfD& s, e3 o, e3 d, double& t) {
+    if (s.type == RT_SURF_SPHERE) {
+        const e3 oc = sub(o, E3(s.d[0], s.d[1], s.d[2]));
+        const double a = dotb(d, d);
+        const double b = 2.0 * dotb(d, oc);
+        const double c = dotb(oc, oc) - s.d[4];
+        const double disc = b * b - 4 * a * c;
+        if (disc < 0) return false;
+        const double sq = sqrt(disc);
+        const double t1 = (-b - sq) / (2.0 * a);
+        if (t1 > 0) { t = t1; return true; }
+        const double t2 = (-b + sq) / (2.0 * a);
+        if (t2 > 0) { t = t2; return true; }
+        return false;
+    }
+    if (s.type == RT_SURF_PLANE) {
+        const e3 n = E3(s.d[0], s.d[1], s.d[2]);
+        const double denom = dotb(d, n);
+        if (fabs(denom) < RT_EPS) return false;
+        const double tt = (s.d[3] - dotb(o, n)) / denom;
+        if (tt > 0) { t = tt; return true; }
+        return false;
+    }
+    double t_near = -INFINITY, t_far = INFINITY;
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double da = comp(d, a), oa = comp(o, a), lo = s.d[a], hi = s.d[3 + a];
+        if (fabs(da) < RT_EPS) {
+            if (oa < lo || oa > hi) miss = true;
+        } else {
+            double t1 = (lo - oa) / da, t2 = (hi - oa) / da;
+            if (t1 > t2) { const double w = t1; t1 = t2; t2 = w; }
+            if (t1 > t_near) t_near = t1;
+            if (t2 < t_far) t_far = t2;
+            if (t_near > t_far) miss = true;
+        }
+    }
+    if (miss || t_far < 0) return false;
+    t = t_near > 0 ? t_near : t_far;
+    return true;
+}
+
 }  // namespace rtx
 
 #pragma clang fp contract(fast)

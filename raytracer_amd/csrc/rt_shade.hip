@@ -206,6 +206,18 @@ __device__ __forceinline__ bool load_chunk(const ShadeQueue& q, uint32_t base, u
     return true;
 }
 
+// Appends the (shade slot, light word) pairs of the lanes with `pred` to the list of k_shade_exact (all 64 lanes call
+// it).  Entries beyond the capacity are only counted: the host then enlarges the list and renders the band again.
+__device__ __forceinline__ void list_pairs(const ShadeArgs& a, bool pred, uint32_t slot, uint32_t light_word) {
+    const unsigned long long em = __ballot(pred);
+    if (!em) return;
+    uint32_t e0 = 0;
+    if ((threadIdx.x & 63) == 0) e0 = atomicAdd(a.exact_count, (uint32_t)__popcll(em));
+    e0 = __builtin_amdgcn_readfirstlane(e0);
+    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+    if (pred && e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(slot, light_word);
+}
+
 // Light factor of one shadow ray (product of the transparencies of the surfaces it crosses,
 // ray_tracer.py:42-46 / :70-78) for scenes of any size.  BATCH picks the multi-sample semantics.
 // Without a grid every surface is tested.  With one, the planes are tested first and the segment then
@@ -339,6 +351,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 
         f3 color = F3(0.f, 0.f, 0.f);
         for (int l = 0; l < L; ++l) {
+            if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
+                list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
+                continue;
+            }
             const LightF lt = a.light[l];
             const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
             const float lc2 = dot(lrel, lrel);
@@ -709,6 +725,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
 
         f3 color = F3(0.f, 0.f, 0.f);
         for (int l = 0; l < L; ++l) {
+            if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
+                list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
+                continue;
+            }
             const LightF lt = a.light[l];
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? (1u << SM) - 1u : 0u;  // surfaces the generic loop has to test for this (wave, light)
@@ -1207,6 +1227,94 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
 // correction: for every sample that enters the sphere steeply and that the float64 quadratic finds blocked, the
 // light factor of the other surfaces (generic FP32 forms) times (transparency - 1).  One wave per pair, the lanes
 // share the N x N samples; most pairs have few such samples (a wide light low over the horizon of the hit) or none.
+// One (hit, light) pair whose light lies on a surface (ShadeArgs::special), shaded completely by one wave: the lanes
+// share the N x N samples (or all evaluate the single ray); the surfaces the light lies on are tested in float64 with
+// the reference's own operations, the others with the generic FP32 forms, the hit's own sphere as in the correction
+// path below.  Such scenes are rare and their reference images are noise where this matters; nothing is tuned here.
+__device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slot, int l, int N, float invN, double inv_n64, uint32_t lane) {
+    const HitRec h = load_hit(a.q, slot);
+    const f3 P = h.P;
+    const uint32_t flags = h.flags;
+    const unsigned long long special = a.special[l];
+    const bool own_valid = !(flags & HF_NO_OWN);
+    const bool own_special = own_valid && ((special >> h.own_id) & 1ull);
+    const int own_id = (own_valid && !own_special) ? h.own_id : -1;   // a special own surface is tested like any other, in float64
+    const SurfF own_sf = a.surf[h.own_id];
+    const MatF m = a.mat[own_sf.mat];
+    const LightF lt = a.light[l];
+    const double* light64 = a.light64 + (size_t)l * 4;
+    const double* p64 = a.q.p64 + (size_t)slot * 3;
+    const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);
+    const float inward_limit = -0.2f * own_sf.c.x;
+    const bool own_exact = own_id >= 0 && (flags & HF_EXACT) && own_sf.type == RT_SURF_SPHERE;
+    const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
+    const float lc2 = dot(lrel, lrel);
+    const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
+    const f3 ldir = lrel * linv;
+    float ratio;
+    if (lt.point_path) {
+        // ---- one ray to the light centre (ray_tracer.py:36-48)
+        float f = shadow_factor<false>(a, P, ldir, lc2 * linv, own_id, h.nrm, flags, ~special);
+        if (own_exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
+            rtx::own_sphere_blocks_centre(p64, light64, a.surf64[own_id]))
+            f *= own_sf.b.w;
+        const rtx::e3 P64 = rtx::E3(p64[0], p64[1], p64[2]);
+        const rtx::e3 to_light = rtx::sub(rtx::E3(light64[0], light64[1], light64[2]), P64);
+        const rtx::e3 d64 = rtx::normalize(to_light);
+        const double dist64 = sqrt(rtx::dotb(to_light, to_light));
+        for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
+            const int s = (int)__builtin_ctzll(mm);
+            double t;
+            if (rtx::scalar_t(a.surf64[s], P64, d64, t) && RT_EPS < t && t < dist64) f *= a.surf[s].transp;
+        }
+        ratio = f;
+    } else {
+        const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);
+        const f3 right = normalize(cross(ldir, perp));
+        const f3 up = normalize(cross(right, ldir));
+        const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
+        const rtx::OwnSphere os = rtx::own_sphere_setup(p64, light64);
+        float sum = 0.f;
+        for (uint32_t s_idx = lane; s_idx < (uint32_t)(N * N); s_idx += 64u) {
+            const int i = (int)(s_idx / (uint32_t)N), j = (int)(s_idx % (uint32_t)N);
+            uint32_t ub, vb;
+            rt_sample_bits(key, s_idx, ub, vb);
+            const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
+            const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
+            const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
+            const float d2 = dot(sv, sv);
+            const float dinv = __frsqrt_rn(d2);
+            const f3 w = sv * dinv;
+            float f = shadow_factor<true>(a, P, w, d2 * dinv, own_id, h.nrm, flags, ~special);
+            if (own_exact && (flags & HF_CBATCH_POS) && dot(w, ov) < inward_limit &&
+                rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
+                f *= own_sf.b.w;
+            if (f != 0.f) {
+                rtx::e3 d64; double dist64;
+                rtx::sample_ray(os, light64, N, inv_n64, i, j, ub, vb, d64, dist64);
+                for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
+                    const int s = (int)__builtin_ctzll(mm);
+                    const double t = rtx::batch_t(a.surf64[s], os.P, d64);
+                    if (t > RT_EPS && t < dist64) f *= a.surf[s].transp;
+                }
+            }
+            sum += f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+        ratio = sum / (float)(N * N);
+    }
+    if (lane == 0) {
+        f3 color = F3(0.f, 0.f, 0.f);
+        phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+        if (color.x != 0.f || color.y != 0.f || color.z != 0.f) {
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], (double)(h.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], (double)(h.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(h.wgt.z * color.z));
+        }
+    }
+}
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     const uint32_t listed = *a.exact_count;
     const uint32_t n_items = listed < a.exact_capacity ? listed : a.exact_capacity;
@@ -1230,8 +1338,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     for (uint32_t it = b0; it < b0 + BATCH && it < n_items; ++it) {
         const uint2 e = a.exact[it];
         const uint32_t slot = __builtin_amdgcn_readfirstlane(e.x);
-        const int l = (int)__builtin_amdgcn_readfirstlane(e.y);
-        if (slot != RT_NULL_HIT) {
+        const uint32_t lword = __builtin_amdgcn_readfirstlane(e.y);
+        const int l = (int)(lword & ~RT_PAIR_FULL);
+        if (slot != RT_NULL_HIT && (lword & RT_PAIR_FULL)) {
+            shade_pair_full(a, slot, l, N, invN, inv_n64, lane);
+        } else if (slot != RT_NULL_HIT) {
             const HitRec h = load_hit(a.q, slot);
             const f3 P = h.P;
             const int own_id = h.own_id;

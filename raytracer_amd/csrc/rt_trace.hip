@@ -360,7 +360,7 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
         const bool hit = active && bs >= 0;
         HitFrame f;
         f.P = D3(0, 0, 0); f.n = D3(0, 0, 0); f.flags = 0; f.mat = 0;
-        if (hit) f = hit_frame(a.surf[bs], o, d, best, bcode);
+        if (hit) { f = hit_frame(a.surf[bs], o, d, best, bcode); if (a.fp.all_p64) f.flags |= HF_EXACT; }
         const d3 P = f.P, n = f.n;
         const MatF m = a.mat[f.mat];
 
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             const bool hit = have && bs >= 0;
             HitFrame f;
             f.P = D3(0, 0, 0); f.n = D3(0, 0, 0); f.flags = 0; f.mat = 0;
-            if (hit) f = hit_frame(use_grid ? a.surf[bs] : tile[bs], o, d, best, bcode);
+            if (hit) { f = hit_frame(use_grid ? a.surf[bs] : tile[bs], o, d, best, bcode); if (a.fp.all_p64) f.flags |= HF_EXACT; }
             const MatF m = a.mat[f.mat];
             if (a.dbg.capacity) {
                 uint32_t slot = wave_append(a.dbg.count, have);

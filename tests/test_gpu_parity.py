@@ -568,9 +568,9 @@ def _edge_scene_text(seed, lights_on_surfaces=False):
         else:
             lines.append(f"box {q(-2.5, 2.5)!r} {q(-0.5, 2)!r} {q(-3, 2)!r} {q(0.3, 1.4)!r} {m()}")
     for _ in range(int(rng.integers(1, 4))):
-        # a light lying exactly ON a surface is left out by default: whether a shadow ray towards it counts that
-        # surface (t < dist with t == dist up to rounding) is decided by the last bit of the reference's float64
-        # arithmetic -- its own image is salt-and-pepper noise there, which no FP32 evaluation reproduces
+        # lights lying exactly ON a surface are a family of their own (4): whether a shadow ray towards one counts
+        # that surface (t < dist with t == dist up to rounding) is decided by the last bit of the reference's float64
+        # arithmetic -- its own image is salt-and-pepper noise there, and only a float64 evaluation reproduces it
         where = pick("free", "free", "in_sphere", "in_box", "on_box" if lights_on_surfaces else "free", "far")
         pos = {"free": (q(-4, 4), q(2, 6), q(-2, 5)), "in_sphere": (cx, cy, cz), "in_box": (bx, by, bz),
                "on_box": (bx, by + be / 2, bz), "far": (q(-400, 400), 900.0, q(-400, 400))}[where]
@@ -716,6 +716,45 @@ def test_twelve_surfaces_use_the_wide_register_resident_kernels(renderer, oracle
         classes[flags] = st["wave_light"]
     assert sum(classes[0][:5]) > 0 and sum(classes[1][:7]) == 0     # classified by the fast kernel / not at all
     assert sum(classes[2][:5]) == 0 and classes[2][5] > 0           # brute force: every pair through the generic loop
+
+
+@pytest.mark.parametrize("seed", [5000, 5008, 5061, 5074, 5080, 5086, 5105, 5108])
+def test_lights_lying_on_box_faces(renderer, oracle, tmp_path, seed):
+    """A shadow ray towards a light that lies ON a surface meets that surface at t = dist up to rounding; the reference
+    decides `t < dist` (ray_tracer.py:43, :71) by the last bit of its float64 arithmetic, so its image is noise there.
+    Pairs with such a light are shaded with those surfaces tested in float64, the reference's operations repeated."""
+    sc = R.parse_scene_file(write_scene(tmp_path, _random_scene_text(seed, family=4)))
+    w, h = 96, 64
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=seed - 5000, threads=THREADS)
+    _, u8, st = renderer.render_rows(w, h, seed=seed - 5000)
+    assert counters_of(st) == cnt
+    m = CI.metrics(np.uint8(ref), u8)
+    assert m["pixels_beyond_1lsb"] <= 2, m
+
+
+@pytest.mark.parametrize("n,radius", [(1, 0.5), (3, 0.0), (4, 1.5)])
+def test_lights_on_a_ceiling_a_ball_and_a_box(renderer, oracle, tmp_path, n, radius):
+    """Lamps placed exactly on the ceiling plane, on a sphere and on a box face, single-ray and sampled: register-
+    resident kernels, any-size kernel and brute force all hand these pairs to the float64 path."""
+    text = (f"cam 0 1.5 6  0 1.2 0  0 1 0  1.4 1.6\nset 0.2 0.3 0.5 {n} 3\n"
+            "mtl 0.7 0.7 0.7  0.3 0.3 0.3  0 0 0  10 0\nmtl 0.8 0.4 0.3  1 1 1  0.3 0.3 0.3  40 0\n"
+            "mtl 0.3 0.5 0.8  1 1 1  0 0 0  20 0.5\n"
+            "pln 0 1 0 0 1\npln 0 -1 0 -4 1\npln 0 0 1 -5 1\n"
+            "sph -1.5 1 0 1 2\nsph 1.6 0.8 0.5 0.8 3\nbox 0 0.5 -2 1 2\n"
+            f"lgt 0.5 4 1  1 0.9 0.8  1 0.8 {radius}\n"          # on the ceiling plane y = 4
+            f"lgt -1.5 2 0  0.5 0.6 1  0.7 1 {radius}\n"          # on top of the first sphere
+            f"lgt 0 1 -2  0.9 0.5 0.5  1 0.6 {radius}\n")         # on the top face of the box
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    renderer.set_scene(sc)
+    w, h = 96, 64
+    ref, cnt = oracle.render_frame(sc, w, h, seed=6, threads=THREADS)
+    for flags in (0, 1, 2):
+        _, u8, st = renderer.render_rows(w, h, seed=6, flags=flags)
+        assert counters_of(st) == cnt
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] <= 1, (flags, m)
+        assert st["wave_light"][7] >= 3 * st["shaded_points"] * 0.99     # every (hit, light) pair went the float64 way
 
 
 def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
