@@ -130,7 +130,8 @@ typedef struct rt_stats {
                                  [5] generic loop (every ray against every surface);
                                  [6] single-ray path (N == 1 or shadow_intensity == 0);
                                  [7] not a wavefront class: (hit, light) pairs whose own-sphere samples were
-                                     evaluated in float64 (hits on a sphere with c > 0, raytracer_amd/csrc/rt_exact.h) */
+                                     evaluated in float64 (hits on a sphere with c > 0; lights lying on a surface:
+                                     raytracer_amd/csrc/rt_exact.h) */
 } rt_stats;
 
 typedef struct rt_handle rt_handle;
