@@ -20,6 +20,11 @@
 //           single-ray path: not blocked when the f64 hit point lies outside the face
 // Everything else is the ordinary test with the literal window (1e-6, distance).
 //
+// Two decisions go back to float64 (rt_exact.h, k_shade_exact), because the reference takes them by the last bits
+// of its arithmetic: the "c > 0" case of the sphere rule for samples that enter the sphere steeply (the rule then
+// holds only if the float64 quadratic still resolves the near root), and every surface a light lies ON (a ray
+// towards that light meets the surface at t = distance up to rounding).
+//
 // Reference: ray_tracer.py:15-85 (shadow ratio, both paths), :88-106 (intensity),
 // :129-171 (Phong), light.py:13-65 (basis + samples), surfaces/*.py intersect_batch
 // (multi-sample path) and intersect (single-ray path).
