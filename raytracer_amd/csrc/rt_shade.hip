@@ -1278,7 +1278,8 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
         const f3 right = normalize(cross(ldir, perp));
         const f3 up = normalize(cross(right, ldir));
         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-        const rtx::OwnSphere os = rtx::own_sphere_setup(p64, light64);
+        rtx::OwnSphere os;        // float64 hit point and light basis: set up when the first sample needs them
+        bool have_os = false;
         float sum = 0.f;
         for (uint32_t s_idx = lane; s_idx < (uint32_t)(N * N); s_idx += 64u) {
             const int i = (int)(s_idx / (uint32_t)N), j = (int)(s_idx % (uint32_t)N);
@@ -1290,18 +1291,32 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
             const float d2 = dot(sv, sv);
             const float dinv = __frsqrt_rn(d2);
             const f3 w = sv * dinv;
-            float f = shadow_factor<true>(a, P, w, d2 * dinv, own_id, h.nrm, flags, ~special);
-            if (own_exact && (flags & HF_CBATCH_POS) && dot(w, ov) < inward_limit &&
-                rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb))
-                f *= own_sf.b.w;
-            if (f != 0.f) {
-                rtx::e3 d64; double dist64;
-                rtx::sample_ray(os, light64, N, inv_n64, i, j, ub, vb, d64, dist64);
-                for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
-                    const int s = (int)__builtin_ctzll(mm);
+            const float dist = d2 * dinv;
+            float f = shadow_factor<true>(a, P, w, dist, own_id, h.nrm, flags, ~special);
+            if (own_exact && (flags & HF_CBATCH_POS) && dot(w, ov) < inward_limit) {
+                if (!have_os) { os = rtx::own_sphere_setup(p64, light64); have_os = true; }
+                if (rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb)) f *= own_sf.b.w;
+            }
+            // The surfaces the light lies on: a sample of a wide light usually ends clear of them (the sample square
+            // is tilted against the surface), and then the FP32 test says the same for a slightly shorter and a
+            // slightly longer ray; only where those two differ is the end point close enough for float64 to matter.
+            // (A hit ON such a surface always takes the float64 test: FP32 has no rule for it here.)
+            bool have_ray = false;
+            rtx::e3 d64 = rtx::E3(0, 0, 1); double dist64 = 0;
+            for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
+                const int s = (int)__builtin_ctzll(mm);
+                const SurfF sf = a.surf[s];
+                const bool own_here = own_special && sf.pad == own_sf.pad;
+                const bool b_short = surface_blocks<true>(sf, P, w, dist * 0.9998f, false, h.nrm, flags);
+                const bool b_long = surface_blocks<true>(sf, P, w, dist * 1.0002f, false, h.nrm, flags);
+                bool blk = b_short;
+                if (own_here || b_short != b_long) {
+                    if (!have_os) { os = rtx::own_sphere_setup(p64, light64); have_os = true; }
+                    if (!have_ray) { rtx::sample_ray(os, light64, N, inv_n64, i, j, ub, vb, d64, dist64); have_ray = true; }
                     const double t = rtx::batch_t(a.surf64[s], os.P, d64);
-                    if (t > RT_EPS && t < dist64) f *= a.surf[s].transp;
+                    blk = t > RT_EPS && t < dist64;
                 }
+                if (blk) f *= sf.transp;
             }
             sum += f;
         }
@@ -1329,11 +1344,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     // the pairs asked for, listed or not: the host compares it with the capacity
     if (blockIdx.x == 0 && threadIdx.x == 0 && listed) atomicAdd(&a.counters[CNT_EXACT], (unsigned long long)listed);
-    // a wave takes 2 pairs at a time, the first batch by its own index (a wave with nothing to do leaves without
-    // touching the shared counter: usually there are fewer batches than waves), the following ones from the counter
-    constexpr uint32_t BATCH = 2;
+    // a wave takes a batch of pairs at a time, the first batch by its own index (a wave with nothing to do leaves
+    // without touching the shared counter: usually there are fewer batches than waves), the following ones from the
+    // counter.  Two pairs per batch when pairs are few; when every hit is listed (a light on a surface) about a quarter
+    // of a wave's share, because one counter word sustains only ~90 atomics/us.
     const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    const uint32_t BATCH = max(2u, min(4096u, n_items / (n_waves * 4u) + 1u));
     auto next_batch = [&]() {
         uint32_t v = 0;
         if (lane == 0) v = atomicAdd(a.work3, BATCH);
