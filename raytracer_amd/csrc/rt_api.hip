@@ -710,8 +710,8 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_light64, light64.data(), sizeof(double) * light64.size(), hipMemcpyHostToDevice));
     int rc = build_grid(h, sd, S);
     if (rc != RT_OK) return rc;
-    // lights whose centre lies on a surface (ShadeArgs::special); scenes without a grid and of up to 64 surfaces
-    if (!h->grid.cell_start && S <= 64) {
+    // lights whose centre lies on a surface (ShadeArgs::special); scenes of up to 64 surfaces
+    if (S <= 64) {
         std::vector<unsigned long long> special((size_t)std::max(L, 1), 0ull);
         bool any = false;
         for (int l = 0; l < L; ++l) {

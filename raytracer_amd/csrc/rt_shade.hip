@@ -249,7 +249,7 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
     // surfaces with the same geometry as the hit's own one (SurfF::pad names the first of them) start on the ray
     // origin just like it and follow the same rule
     const int own_grp = own_id >= 0 ? a.surf[own_id].pad : -1;
-    if (!g.cell_start) {
+    if (!g.cell_start || a.fp.n_surfaces <= 64) {   // (a grid over so few surfaces only exists when a test forces it)
         const int S = a.fp.n_surfaces;
         if (S <= 64) {   // only the surfaces some lane of the wave can reach from this light (wave-uniform mask)
             for (unsigned long long m = reach_mask & (S == 64 ? ~0ull : (1ull << S) - 1ull); m; m &= m - 1ull) {
