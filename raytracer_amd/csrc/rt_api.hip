@@ -314,6 +314,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;
         sa.exact = h->d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->exact_capacity; sa.work3 = h->d_qcounts + 47;
+        sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));

@@ -193,6 +193,8 @@ struct ShadeArgs {
     uint32_t* exact_count;
     uint32_t exact_capacity;
     uint32_t* work3;     // shared work counter of k_shade_exact
+    uint32_t* full_count; // RT_PAIR_FULL entries: they fill the same list from its END downwards (one lane each in k_shade_exact)
+    uint32_t* work4;     // ... and their work counter
     float exact_min;     // a back-lit pair goes to k_shade_exact only if its specular term can exceed this (full scale = 1)
     // Lights whose centre lies on (within 1e-3 of) a surface: bit s of special[l] names the surface (null: the scene has
     // none; scenes of up to 64 surfaces only).  A shadow ray towards such a light meets that surface at t = dist up to

@@ -213,14 +213,16 @@ __device__ __forceinline__ bool load_chunk(const ShadeQueue& q, uint32_t base, u
 
 // Appends the (shade slot, light word) pairs of the lanes with `pred` to the list of k_shade_exact (all 64 lanes call
 // it).  Entries beyond the capacity are only counted: the host then enlarges the list and renders the band again.
+// light_word (wave-uniform) with RT_PAIR_FULL: the entries go to the END of the list, downwards (their own counter).
 __device__ __forceinline__ void list_pairs(const ShadeArgs& a, bool pred, uint32_t slot, uint32_t light_word) {
     const unsigned long long em = __ballot(pred);
     if (!em) return;
+    const bool full = (light_word & RT_PAIR_FULL) != 0u;
     uint32_t e0 = 0;
-    if ((threadIdx.x & 63) == 0) e0 = atomicAdd(a.exact_count, (uint32_t)__popcll(em));
+    if ((threadIdx.x & 63) == 0) e0 = atomicAdd(full ? a.full_count : a.exact_count, (uint32_t)__popcll(em));
     e0 = __builtin_amdgcn_readfirstlane(e0);
     const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-    if (pred && e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(slot, light_word);
+    if (pred && e0 + pre < a.exact_capacity) a.exact[full ? a.exact_capacity - 1u - (e0 + pre) : e0 + pre] = make_uint2(slot, light_word);
 }
 
 // Light factor of one shadow ray (product of the transparencies of the surfaces it crosses,
@@ -1232,11 +1234,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
 // correction: for every sample that enters the sphere steeply and that the float64 quadratic finds blocked, the
 // light factor of the other surfaces (generic FP32 forms) times (transparency - 1).  One wave per pair, the lanes
 // share the N x N samples; most pairs have few such samples (a wide light low over the horizon of the hit) or none.
-// One (hit, light) pair whose light lies on a surface (ShadeArgs::special), shaded completely by one wave: the lanes
-// share the N x N samples (or all evaluate the single ray); the surfaces the light lies on are tested in float64 with
-// the reference's own operations, the others with the generic FP32 forms, the hit's own sphere as in the correction
-// path below.  Such scenes are rare and their reference images are noise where this matters; nothing is tuned here.
-__device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slot, int l, int N, float invN, double inv_n64, uint32_t lane) {
+// One (hit, light) pair whose light lies on a surface (ShadeArgs::special), shaded completely by ONE LANE (every hit of
+// the frame has such a pair, so there are plenty): the surfaces the light lies on are tested in float64 with the
+// reference's own operations where FP32 cannot tell, the others with the generic FP32 forms, the hit's own sphere as
+// in the correction path below.
+__device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slot, int l, int N, float invN, double inv_n64) {
     const HitRec h = load_hit(a.q, slot);
     const f3 P = h.P;
     const uint32_t flags = h.flags;
@@ -1281,7 +1283,7 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
         rtx::OwnSphere os;        // float64 hit point and light basis: set up when the first sample needs them
         bool have_os = false;
         float sum = 0.f;
-        for (uint32_t s_idx = lane; s_idx < (uint32_t)(N * N); s_idx += 64u) {
+        for (uint32_t s_idx = 0; s_idx < (uint32_t)(N * N); ++s_idx) {
             const int i = (int)(s_idx / (uint32_t)N), j = (int)(s_idx % (uint32_t)N);
             uint32_t ub, vb;
             rt_sample_bits(key, s_idx, ub, vb);
@@ -1320,11 +1322,9 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
             }
             sum += f;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
         ratio = sum / (float)(N * N);
     }
-    if (lane == 0) {
+    {
         f3 color = F3(0.f, 0.f, 0.f);
         phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
         if (color.x != 0.f || color.y != 0.f || color.z != 0.f) {
@@ -1336,14 +1336,16 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
 }
 
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
-    const uint32_t listed = *a.exact_count;
+    const uint32_t listed = *a.exact_count, listed_full = *a.full_count;
     const uint32_t n_items = listed < a.exact_capacity ? listed : a.exact_capacity;
+    const uint32_t n_full = listed_full < a.exact_capacity ? listed_full : a.exact_capacity;
     const int N = a.fp.n_shadow;
     const float invN = 1.0f / (float)N;
     const double inv_n64 = (N & (N - 1)) == 0 ? 1.0 / (double)N : 0.0;   // exact reciprocal of a power of two (rt_exact.h)
     const uint32_t lane = threadIdx.x & 63;
     // the pairs asked for, listed or not: the host compares it with the capacity
-    if (blockIdx.x == 0 && threadIdx.x == 0 && listed) atomicAdd(&a.counters[CNT_EXACT], (unsigned long long)listed);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (listed || listed_full))
+        atomicAdd(&a.counters[CNT_EXACT], (unsigned long long)listed + (unsigned long long)listed_full);
     // a wave takes a batch of pairs at a time, the first batch by its own index (a wave with nothing to do leaves
     // without touching the shared counter: usually there are fewer batches than waves), the following ones from the
     // counter.  Two pairs per batch when pairs are few; when every hit is listed (a light on a surface) about a quarter
@@ -1362,9 +1364,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
         const uint32_t slot = __builtin_amdgcn_readfirstlane(e.x);
         const uint32_t lword = __builtin_amdgcn_readfirstlane(e.y);
         const int l = (int)(lword & ~RT_PAIR_FULL);
-        if (slot != RT_NULL_HIT && (lword & RT_PAIR_FULL)) {
-            shade_pair_full(a, slot, l, N, invN, inv_n64, lane);
-        } else if (slot != RT_NULL_HIT) {
+        if (slot != RT_NULL_HIT && !(lword & RT_PAIR_FULL)) {
             const HitRec h = load_hit(a.q, slot);
             const f3 P = h.P;
             const int own_id = h.own_id;
@@ -1422,6 +1422,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
                     unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(h.wgt.z * color.z));
                 }
             }
+        }
+    }
+    // ---- pairs to be shaded completely (a light on a surface): one lane each, 64 consecutive entries per wave,
+    //      taken from the end of the list; groups of entries are handed out like the batches above
+    const uint32_t n_groups = (n_full + 63u) >> 6;
+    const uint32_t GROUPS = max(1u, min(256u, n_groups / (n_waves * 4u) + 1u));
+    auto next_groups = [&]() {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(a.work4, GROUPS);
+        return (uint32_t)__builtin_amdgcn_readfirstlane(v) + n_waves * GROUPS;
+    };
+    for (uint32_t g0 = wave * GROUPS; g0 < n_groups; g0 = next_groups())
+    for (uint32_t g = g0; g < g0 + GROUPS && g < n_groups; ++g) {
+        const uint32_t i = g * 64u + lane;
+        if (i < n_full) {
+            const uint2 e = a.exact[a.exact_capacity - 1u - i];
+            if (e.x != RT_NULL_HIT && (e.y & RT_PAIR_FULL)) shade_pair_full(a, e.x, (int)(e.y & ~RT_PAIR_FULL), N, invN, inv_n64);
         }
     }
 }
