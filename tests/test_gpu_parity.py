@@ -757,6 +757,29 @@ def test_lights_on_a_ceiling_a_ball_and_a_box(renderer, oracle, tmp_path, n, rad
         assert st["wave_light"][7] >= 3 * st["shaded_points"] * 0.99     # every (hit, light) pair went the float64 way
 
 
+def test_pair_list_grows_when_every_hit_is_listed(oracle, tmp_path, monkeypatch):
+    """A lamp on the ceiling plane lists every (hit, light) pair; with a list far too short the call counts the
+    demand, rebuilds the list and renders again: the oracle's image, the same counters."""
+    text = ("cam 0 1.5 6  0 1.2 0  0 1 0  1.4 1.6\nset 0.2 0.3 0.5 3 3\n"
+            "mtl 0.7 0.7 0.7  0.3 0.3 0.3  0 0 0  10 0\nmtl 0.3 0.5 0.8  1 1 1  0.2 0.2 0.2  20 0.5\n"
+            "pln 0 1 0 0 1\npln 0 -1 0 -4 1\nsph -1 1 0 1 2\nbox 1 0.5 -1 1 1\n"
+            "lgt 0.5 4 1  1 0.9 0.8  1 0.8 1.5\nlgt -3 3 3  0.5 0.6 1  0.7 1 1\n")
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    monkeypatch.setenv("RT_EXACT_LIST", "300")
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(sc)
+        w, h = 96, 64
+        ref, cnt = oracle.render_frame(sc, w, h, seed=1, threads=THREADS)
+        _, u8, st = r.render_rows(w, h, seed=1)
+        assert counters_of(st) == cnt
+        assert st["wave_light"][7] >= st["shaded_points"] > 300
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] == 0, m
+    finally:
+        r.close()
+
+
 def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
     """Hit points tens of thousands of units away (a level camera over an infinite plane): their shadow rays
     graze the objects near the origin from afar, where the literal FP32 sphere quadratic is pure cancellation."""
