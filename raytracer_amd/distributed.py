@@ -162,7 +162,7 @@ class DistributedRenderer:
 
     ``pipelines`` > 1: queued frames (``enqueue``) alternate over that many independent renderer handles, each with
     its own stream, tile and gather buffers, so the first kernels of frame k+1 fill the GPU while the last, long
-    work items of frame k drain (two pipelines: 10 % more frames per second on a full 4K frame, 29 % on an eighth
+    work items of frame k drain (two pipelines: 10 % more frames per second on a full 4K frame, 41 % on an eighth
     of it; a third one did not help).  Frame k is complete when ``finish()`` returns.
     """
 
