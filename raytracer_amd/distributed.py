@@ -138,11 +138,12 @@ def concurrent_streams(torch, device, n, candidates=12):
     """
     kept = []
     with torch.cuda.device(device):
+        can_probe = hasattr(torch.cuda, "_sleep")   # the spin kernel of torch; without it the first n streams are taken
         for _ in range(candidates):
             if len(kept) == n:
                 break
             c = torch.cuda.Stream(device=device)
-            if all(_overlap(torch, c, k) for k in kept):
+            if not can_probe or all(_overlap(torch, c, k) for k in kept):
                 kept.append(c)
         while len(kept) < n:    # no more independent queues: share
             kept.append(torch.cuda.Stream(device=device))
