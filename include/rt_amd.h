@@ -161,6 +161,22 @@ int rt_render(rt_handle* h, const rt_render_params* p, float* host_rgb_f32, uint
 int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
                      void* stream, rt_stats* stats);
 
+/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same contract as rt_render_device (device
+ * output pointers, work on `stream`, returns after the stream has drained), but the ray / shade queues, the
+ * accumulators and the work lists live in a static __device__ array of RT_NOALLOC_SCRATCH_BYTES that the library
+ * holds on every GPU it runs on until the process ends, and the call makes no hipMalloc / hipFree (rt_create
+ * and rt_set_scene, the set-up calls, still allocate).  Limits: at most RT_NOALLOC_MAX_PIXELS selected pixels per
+ * call, and the queues cannot grow -- a selection above the limit, a scene whose queues do not fit, or a ray
+ * tree that outgrows them (a deep tree of reflecting AND transparent hits) fails with RT_ERR_UNSUPPORTED /
+ * RT_ERR_QUEUE and a message that says so; render such frames with rt_render_device.  All handles of a GPU share
+ * that one array, and it keeps the last call's contents (the call clears what has to start at zero): calls that
+ * overlap on one GPU -- two handles, two threads, two streams -- race and must be serialised by the caller.     */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+#define RT_NOALLOC_MAX_PIXELS (1 << 17)
+int rt_render_device_noalloc(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
+                             void* stream, rt_stats* stats);
+
 /* Frame loops that must not stall on the host between frames (serving, the multi-GPU
  * gather): rt_render_enqueue puts one frame on `stream` like rt_render_device and returns
  * at once; rt_render_wait blocks until every enqueued frame is done, reports whether one

@@ -46,8 +46,36 @@ constexpr int kAsyncDepth = 8;         // frames rt_render_enqueue keeps in flig
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
 constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
+constexpr size_t kHostRows = 16384;    // rows of the pinned row-list staging buffer made at rt_create (grows on demand)
 
 }  // namespace
+
+// Frame memory of rt_render_device_noalloc: one array per GPU that loads this library, held until the process ends.
+// In host code the name is only a stand-in for the symbol: rt_create resolves this device's copy once
+// (hipGetSymbolAddress, kept in g_scratch_ptr) and everything that touches the memory uses that pointer.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[64] = {};   // per device ordinal
+
+// Device memory of one row band: the ray / shade queues, the accumulators, the work lists.  Normally carved out of one
+// hipMalloc'd arena that grows on demand; rt_render_device_noalloc points the same fields into the static scratch array.
+struct FrameMem {
+    size_t band_capacity = 0;        // pixels
+    RayQueue rq[2]{};
+    ShadeQueue sq{};
+    double* d_accum = nullptr;
+    size_t accum_zero_prefix = 0;    // accumulator values [0, prefix) are known to be zero (k_resolve clears what it reads)
+    uint2* d_deferred = nullptr;
+    uint2* d_exact = nullptr;        // (slot, light) list of k_shade_exact
+    uint32_t exact_capacity = 0;
+    int arena_lights = 0;
+    bool arena_has_rays = false;     // the arena holds full-size ray queues
+    int32_t* d_row_y = nullptr;
+    size_t row_y_cap = 0;
+    void* arena = nullptr;           // one allocation behind all queue arrays
+    RayQueue stack{};                // run-to-completion ray tree: parked children, [level][thread]
+    void* stack_mem = nullptr;
+    size_t stack_slots = 0;
+};
 
 struct rt_handle {
     int device = 0;
@@ -71,15 +99,17 @@ struct rt_handle {
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
 
-    // frame buffers, sized for band_capacity pixels
-    size_t band_capacity = 0;        // pixels
+    FrameMem fm{};                   // queues and accumulators of a band (rt_render_device_noalloc swaps in a view of the static scratch)
+    bool no_alloc = false;           // set while rt_render_device_noalloc runs: nothing may be allocated or grown
     size_t max_band_pixels = 3840u * 2160u;
-    RayQueue rq[2]{};
-    ShadeQueue sq{};
     HitDebug dbg{};
-    double* d_accum = nullptr;
     unsigned long long* d_counters = nullptr;  // CNT_N statistics words, directly followed by d_qcounts (one memset per band)
     uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
+    unsigned long long* host_counters = nullptr;  // pinned: the band's counters land here (no staging by the runtime)
+    int32_t* host_rows = nullptr;    // pinned copy of the row list on the device (the upload reads it in stream order)
+    size_t host_rows_cap = 0;
+    hipStream_t rows_stream = nullptr;  // stream the last upload of the row list was ordered on
+    void* scratch = nullptr;         // this device's copy of the static scratch array (rt_render_device_noalloc)
     // uniform grid over the bounded surfaces (large scenes)
     SceneGrid grid{};
     uint32_t* d_grid_mem = nullptr;
@@ -88,25 +118,13 @@ struct rt_handle {
     int grid_override = -1;          // RT_GRID: -1 automatic (more than kGridMinSurfaces surfaces), 0 never, 1 always
     // run-to-completion tail of the ray tree (k_trace_tail)
     bool both_children = false;      // some material spawns a reflection and a transparency child
-    RayQueue stack{};                // parked children, [level][thread]
-    void* stack_mem = nullptr;
-    size_t stack_slots = 0;
     int tail_override = -1;          // RT_TAIL_FROM: -1 automatic, 0 never, d >= 1 from depth d on
-    size_t accum_zero_prefix = 0;    // accumulator values [0, prefix) are known to be zero (k_resolve clears what it reads)
     std::vector<int32_t> rows_on_device;  // what d_row_y holds
-    uint2* d_deferred = nullptr;
-    uint2* d_exact = nullptr;            // (slot, light) list of k_shade_exact
-    uint32_t exact_capacity = 0;
     size_t exact_want = 0;               // pairs a frame asked for when the list was too short (it is then rebuilt that large)
-    int arena_lights = 0;
-    bool arena_has_rays = false;     // the arena holds full-size ray queues
-    int32_t* d_row_y = nullptr;
-    size_t row_y_cap = 0;
     float* d_out_f32 = nullptr;
     uint8_t* d_out_u8 = nullptr;
     size_t out_cap = 0;              // values
-    void* arena = nullptr;           // one allocation behind all queue arrays
-    hipEvent_t ev[5]{};
+    hipEvent_t ev[6]{};              // [0..3] band stages, [4], [5] begin / end of a synchronous call
     // frames enqueued by rt_render_enqueue and not yet collected
     struct Pending { hipEvent_t ev[4]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
     Pending ring[kAsyncDepth];
@@ -131,15 +149,14 @@ int fail(rt_handle* h, int code, const std::string& msg) {
     } while (0)
 
 void free_frame_buffers(rt_handle* h) {
-    if (h->arena) (void)hipFree(h->arena);
-    h->arena = nullptr;
-    h->band_capacity = 0;
-    h->arena_lights = 0;
-    h->arena_has_rays = false;
-    h->accum_zero_prefix = 0;
+    if (h->fm.arena) (void)hipFree(h->fm.arena);
+    h->fm.arena = nullptr;
+    h->fm.band_capacity = 0;
+    h->fm.arena_lights = 0;
+    h->fm.arena_has_rays = false;
+    h->fm.accum_zero_prefix = 0;
 }
 
-// carve the SoA queues out of one arena
 // Depth from which one k_trace_tail launch replaces the per-level launches (>= depths: never).
 // Whenever the surface list fits one LDS tile the whole tree, camera rays included, runs in one
 // launch: no ray queue traffic, no launch per level (measured 0.45 ms against 0.92 ms on the 4K
@@ -155,51 +172,69 @@ int choose_tail_depth(const rt_handle* h, int depths) {
 // camera rays are enumerated in 8 x 8 pixel tiles; each owns one shade slot (rt_trace.hip: primary_slots)
 size_t primary_slots(size_t width, size_t rows) { return ((width + 7) / 8) * ((rows + 7) / 8) * 64; }
 
+inline size_t al256(size_t b) { return (b + 255) / 256 * 256; }
+
+// Sizes of the queue arrays for a band of `pixels` pixels (one layout for the arena and for the static scratch).
+struct BandLayout { size_t rcap, scap, dcap, ecap, bytes; };
+BandLayout band_layout(size_t pixels, int lights, bool need_rays, size_t ecap_min, size_t ecap_fixed) {
+    BandLayout b{};
+    b.rcap = need_rays ? pixels * kRayFactor : 64;
+    b.scap = pixels * kShadeFactor;
+    b.dcap = (b.scap / 64 + 1) * (size_t)lights;   // every (64-hit chunk, light) pair at most once
+    b.ecap = std::max(ecap_fixed ? ecap_fixed : b.scap / 2, ecap_min);  // pairs needing float64 are rare; a frame that needs more says so
+    b.bytes = 2 * (4 * al256(b.rcap * 16) + al256(b.rcap * 4))     // two ray queues
+            + 4 * al256(b.scap * 16) + al256(b.scap * 24)          // shade queue (+ float64 hit points)
+            + al256(pixels * 3 * 8)                                // accumulators
+            + al256(b.dcap * sizeof(uint2)) + al256(b.ecap * sizeof(uint2));
+    return b;
+}
+
+// carve the SoA queues out of `base` (b.bytes bytes); returns the first byte behind them
+char* carve_band(rt_handle* h, void* base, const BandLayout& b, size_t pixels, int lights, bool need_rays) {
+    char* p = (char*)base;
+    auto take = [&](size_t n) { void* r = p; p += al256(n); return r; };
+    for (int q = 0; q < 2; ++q) {
+        RayQueue& r = h->fm.rq[q];
+        r.oa = (double2*)take(b.rcap * 16); r.ob = (double2*)take(b.rcap * 16); r.oc = (double2*)take(b.rcap * 16);
+        r.tp = (uint4*)take(b.rcap * 16); r.node = (uint32_t*)take(b.rcap * 4);
+        r.count = h->d_qcounts + q;
+        r.capacity = (uint32_t)b.rcap;
+    }
+    ShadeQueue& s = h->fm.sq;
+    s.r0 = (float4*)take(b.scap * 16); s.r1 = (float4*)take(b.scap * 16); s.r2 = (float4*)take(b.scap * 16);
+    s.r3 = (uint4*)take(b.scap * 16);
+    s.p64 = (double*)take(b.scap * 24);
+    s.count = h->d_qcounts + 2;
+    s.capacity = (uint32_t)b.scap;
+    h->fm.d_accum = (double*)take(pixels * 3 * 8);
+    h->fm.d_deferred = (uint2*)take(b.dcap * sizeof(uint2));
+    h->fm.d_exact = (uint2*)take(b.ecap * sizeof(uint2));
+    h->fm.exact_capacity = (uint32_t)std::min<size_t>(b.ecap, 0x7FFFFFFFu);
+    h->fm.band_capacity = pixels;
+    h->fm.arena_lights = lights;
+    h->fm.arena_has_rays = need_rays;
+    h->fm.accum_zero_prefix = 0;
+    return p;
+}
+
 int ensure_band_capacity(rt_handle* h, size_t pixels) {
     const int lights = h->L > 0 ? h->L : 1;
     // the ping-pong ray queues are only needed when some level has a launch of its own
     const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
-    if (pixels <= h->band_capacity && lights <= h->arena_lights && (!need_rays || h->arena_has_rays) &&
-        h->exact_want <= h->exact_capacity) return RT_OK;
-    if (pixels < h->band_capacity) pixels = h->band_capacity;
+    if (pixels <= h->fm.band_capacity && lights <= h->fm.arena_lights && (!need_rays || h->fm.arena_has_rays) &&
+        h->exact_want <= h->fm.exact_capacity) return RT_OK;
+    if (h->no_alloc)
+        return fail(h, RT_ERR_QUEUE, "rt_render_device_noalloc: the frame's ray tree needs larger queues than the static scratch holds "
+                                     "(they cannot grow here): render it with rt_render_device");
+    if (pixels < h->fm.band_capacity) pixels = h->fm.band_capacity;
     if (pixels < kMinArenaPixels) pixels = kMinArenaPixels;  // head-room for deep ray trees of small frames
     free_frame_buffers(h);
-    const size_t rcap = need_rays ? pixels * kRayFactor : 64, scap = pixels * kShadeFactor;
-    auto al = [](size_t b) { return (b + 255) / 256 * 256; };
-    size_t bytes = 0;
-    bytes += 2 * (4 * al(rcap * 16) + al(rcap * 4));     // two ray queues
-    bytes += 4 * al(scap * 16) + al(scap * 24);          // shade queue (+ float64 hit points)
-    bytes += al(pixels * 3 * 8);                        // accumulators
-    const size_t dcap = (scap / 64 + 1) * (size_t)lights; // every (64-hit chunk, light) pair at most once
-    bytes += al(dcap * sizeof(uint2));
-    const size_t ecap = std::max(h->exact_list ? h->exact_list : scap / 2, h->exact_want); // pairs needing float64 are rare; a frame that needs more says so
-    bytes += al(ecap * sizeof(uint2));
+    const BandLayout b = band_layout(pixels, lights, need_rays, h->exact_want, h->exact_list);
     void* base = nullptr;
-    hipError_t e = hipMalloc(&base, bytes);
-    if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(bytes) + " bytes for frame queues failed");
-    h->arena = base;
-    char* p = (char*)base;
-    auto take = [&](size_t b) { void* r = p; p += al(b); return r; };
-    for (int q = 0; q < 2; ++q) {
-        RayQueue& r = h->rq[q];
-        r.oa = (double2*)take(rcap * 16); r.ob = (double2*)take(rcap * 16); r.oc = (double2*)take(rcap * 16);
-        r.tp = (uint4*)take(rcap * 16); r.node = (uint32_t*)take(rcap * 4);
-        r.count = h->d_qcounts + q;
-        r.capacity = (uint32_t)rcap;
-    }
-    ShadeQueue& s = h->sq;
-    s.r0 = (float4*)take(scap * 16); s.r1 = (float4*)take(scap * 16); s.r2 = (float4*)take(scap * 16);
-    s.r3 = (uint4*)take(scap * 16);
-    s.p64 = (double*)take(scap * 24);
-    s.count = h->d_qcounts + 2;
-    s.capacity = (uint32_t)scap;
-    h->d_accum = (double*)take(pixels * 3 * 8);
-    h->d_deferred = (uint2*)take(dcap * sizeof(uint2));
-    h->d_exact = (uint2*)take(ecap * sizeof(uint2));
-    h->exact_capacity = (uint32_t)std::min<size_t>(ecap, 0x7FFFFFFFu);
-    h->band_capacity = pixels;
-    h->arena_lights = lights;
-    h->arena_has_rays = need_rays;
+    hipError_t e = hipMalloc(&base, b.bytes);
+    if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(b.bytes) + " bytes for frame queues failed");
+    h->fm.arena = base;
+    carve_band(h, base, b, pixels, lights, need_rays);
     return RT_OK;
 }
 
@@ -222,21 +257,70 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
 
 struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
 
-int ensure_tail_stack(rt_handle* h, int blocks) {
+void point_tail_stack(rt_handle* h, void* mem, size_t slots) {
+    char* p = (char*)mem;
+    h->fm.stack.oa = (double2*)p; p += slots * 16;
+    h->fm.stack.ob = (double2*)p; p += slots * 16;
+    h->fm.stack.oc = (double2*)p; p += slots * 16;
+    h->fm.stack.tp = (uint4*)p; p += slots * 16;
+    h->fm.stack.node = (uint32_t*)p;
+    h->fm.stack.count = nullptr; h->fm.stack.capacity = (uint32_t)std::min<size_t>(slots, 0xFFFFFFFFu);
+    h->fm.stack_slots = slots;
+}
+
+// Parked children of the run-to-completion ray tree: max_rec slots per thread of the launch.  `blocks` may come back
+// smaller when nothing may be allocated (the launch then covers the band in more passes).
+int ensure_tail_stack(rt_handle* h, int& blocks) {
     if (!h->both_children) return RT_OK;  // no hit can park a child: the kernel gets stack_levels = 0
-    const size_t threads = (size_t)blocks * RT_TAIL_BLOCK, slots = threads * (size_t)std::max(h->R, 1);
-    if (slots <= h->stack_slots) return RT_OK;
-    if (h->stack_mem) (void)hipFree(h->stack_mem);
-    h->stack_mem = nullptr; h->stack_slots = 0;
-    HIP_TRY(h, hipMalloc(&h->stack_mem, slots * 68));
-    char* p = (char*)h->stack_mem;
-    h->stack.oa = (double2*)p; p += slots * 16;
-    h->stack.ob = (double2*)p; p += slots * 16;
-    h->stack.oc = (double2*)p; p += slots * 16;
-    h->stack.tp = (uint4*)p; p += slots * 16;
-    h->stack.node = (uint32_t*)p;
-    h->stack.count = nullptr; h->stack.capacity = (uint32_t)std::min<size_t>(slots, 0xFFFFFFFFu);
-    h->stack_slots = slots;
+    const size_t per_block = (size_t)RT_TAIL_BLOCK * (size_t)std::max(h->R, 1);
+    if ((size_t)blocks * per_block <= h->fm.stack_slots) return RT_OK;
+    if (h->no_alloc) {
+        blocks = (int)std::min<size_t>((size_t)blocks, h->fm.stack_slots / per_block);
+        if (blocks < 1) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: no room in the static scratch for the ray tree's stack "
+                                                           "(scene with reflecting and transparent materials): render it with rt_render_device");
+        return RT_OK;
+    }
+    const size_t slots = (size_t)blocks * per_block;
+    if (h->fm.stack_mem) (void)hipFree(h->fm.stack_mem);
+    h->fm.stack_mem = nullptr; h->fm.stack_slots = 0;
+    HIP_TRY(h, hipMalloc(&h->fm.stack_mem, slots * 68));
+    point_tail_stack(h, h->fm.stack_mem, slots);
+    return RT_OK;
+}
+
+// The device copy of the band's row list (FrameParams::row_y).  The upload reads a pinned host buffer in stream order,
+// so before that buffer is rewritten the stream of the previous upload is drained (the list changes rarely: another
+// selection of rows, or a frame split into bands).
+int upload_rows(rt_handle* h, const int32_t* rows, int n_rows, hipStream_t st) {
+    if (h->rows_on_device.size() == (size_t)n_rows && !std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) return RT_OK;
+    if ((size_t)n_rows > h->host_rows_cap) return fail(h, RT_ERR_INVALID, "row list longer than its staging buffer");
+    if (h->rows_stream) HIP_TRY(h, hipStreamSynchronize(h->rows_stream));
+    if (h->rows_stream != st) HIP_TRY(h, hipStreamSynchronize(st));   // kernels of an earlier band may still read the device copy
+    h->rows_on_device.clear();
+    std::memcpy(h->host_rows, rows, sizeof(int32_t) * n_rows);
+    HIP_TRY(h, hipMemcpyAsync(h->fm.d_row_y, h->host_rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
+    h->rows_stream = st;
+    h->rows_on_device.assign(rows, rows + n_rows);
+    return RT_OK;
+}
+
+// room for `n` rows in the pinned staging buffer and (unless the frame memory is the static scratch) on the device
+int ensure_rows(rt_handle* h, size_t n) {
+    if (n > h->host_rows_cap) {
+        if (h->no_alloc) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: more rows than the row staging buffer holds");
+        if (h->rows_stream) HIP_TRY(h, hipStreamSynchronize(h->rows_stream));
+        if (h->host_rows) (void)hipHostFree(h->host_rows);
+        h->host_rows = nullptr; h->host_rows_cap = 0; h->rows_on_device.clear();
+        HIP_TRY(h, hipHostMalloc((void**)&h->host_rows, sizeof(int32_t) * n));
+        h->host_rows_cap = n;
+    }
+    if (n > h->fm.row_y_cap) {
+        if (h->no_alloc) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: more rows than the static scratch has room for");
+        if (h->fm.d_row_y) (void)hipFree(h->fm.d_row_y);
+        h->fm.d_row_y = nullptr; h->fm.row_y_cap = 0; h->rows_on_device.clear();
+        HIP_TRY(h, hipMalloc(&h->fm.d_row_y, sizeof(int32_t) * n));
+        h->fm.row_y_cap = n;
+    }
     return RT_OK;
 }
 
@@ -250,49 +334,45 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     const size_t pixels = (size_t)n_rows * p->width;
     const size_t slots0 = primary_slots((size_t)p->width, (size_t)n_rows);
     // thin bands pad their tiles up to 8 rows: make room for the camera rays' slots plus as many appended hits
-    if (slots0 * 2 > (size_t)h->sq.capacity) {
+    if (slots0 * 2 > (size_t)h->fm.sq.capacity) {
         int rc = ensure_band_capacity(h, (slots0 * 2 + kShadeFactor - 1) / kShadeFactor);
         if (rc != RT_OK) return rc;
     }
-    h->sq.base = (uint32_t)slots0;
-    if (h->rows_on_device.size() != (size_t)n_rows || std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) {
-        h->rows_on_device.assign(rows, rows + n_rows);  // the copy reads this vector, which outlives the call
-        hipError_t e = hipMemcpyAsync(h->d_row_y, h->rows_on_device.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) h->rows_on_device.clear();
-        HIP_TRY(h, e);
-    }
+    h->fm.sq.base = (uint32_t)slots0;
+    { int rc = upload_rows(h, rows, n_rows, st); if (rc != RT_OK) return rc; }
+    if (h->no_alloc) h->fm.accum_zero_prefix = 0;   // the scratch is shared by every handle of the device: clear what this band adds into
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts, st));
-    if (h->accum_zero_prefix < 3 * pixels) {
-        HIP_TRY(h, hipMemsetAsync(h->d_accum + h->accum_zero_prefix, 0, sizeof(double) * (3 * pixels - h->accum_zero_prefix), st));
+    if (h->fm.accum_zero_prefix < 3 * pixels) {
+        HIP_TRY(h, hipMemsetAsync(h->fm.d_accum + h->fm.accum_zero_prefix, 0, sizeof(double) * (3 * pixels - h->fm.accum_zero_prefix), st));
     }
-    const size_t zero_before = std::max(h->accum_zero_prefix, 3 * pixels);
-    h->accum_zero_prefix = 0;  // dirty until k_resolve has run over this band
+    const size_t zero_before = std::max(h->fm.accum_zero_prefix, 3 * pixels);
+    h->fm.accum_zero_prefix = 0;  // dirty until k_resolve has run over this band
 
     FrameParams fp{};
     fp.width = p->width; fp.height = p->height; fp.band_rows = n_rows;
     fp.max_rec = h->R; fp.n_shadow = h->N; fp.n_surfaces = h->S; fp.n_lights = h->L;
     fp.seed_key = rt_seed_key(p->seed);
     fp.bg[0] = h->bg[0]; fp.bg[1] = h->bg[1]; fp.bg[2] = h->bg[2];
-    fp.row_y = h->d_row_y;
+    fp.row_y = h->fm.d_row_y;
     fp.all_p64 = h->d_special ? 1 : 0;
 
     HIP_TRY(h, hipEventRecord(ev[0], st));
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
     const int tail_from = choose_tail_depth(h, depths);
-    const int tail_blocks = h->n_cu * 2;
+    int tail_blocks = h->n_cu * 2;
     if (tail_from < depths) { int rc = ensure_tail_stack(h, tail_blocks); if (rc != RT_OK) return rc; }
     for (int d = 0; d < depths && d <= tail_from; ++d) {
         TraceArgs ta{};
         ta.fp = fp; ta.cam = h->cam; ta.surf = h->d_surf; ta.mat = h->d_mat; ta.grid = h->grid;
         // every depth has its own counter word (zeroed with the others, once per band): no memset per depth
-        ta.in = h->rq[d & 1]; ta.out = h->rq[(d + 1) & 1];
+        ta.in = h->fm.rq[d & 1]; ta.out = h->fm.rq[(d + 1) & 1];
         ta.in.count = h->d_qcounts + 8 + d; ta.out.count = h->d_qcounts + 8 + d + 1;
-        ta.shade = h->sq;
+        ta.shade = h->fm.sq;
         ta.dbg = debug ? h->dbg : HitDebug{};
-        ta.accum = h->d_accum; ta.npix = pixels; ta.counters = h->d_counters; ta.depth = d;
+        ta.accum = h->fm.d_accum; ta.npix = pixels; ta.counters = h->d_counters; ta.depth = d;
         if (d == tail_from) {
-            ta.stack = h->stack; ta.stack_levels = h->both_children ? (uint32_t)h->R : 0u;
+            ta.stack = h->fm.stack; ta.stack_levels = h->both_children ? (uint32_t)h->R : 0u;
             rt_launch_trace_tail(ta, tail_blocks, st);
             break;
         }
@@ -303,34 +383,35 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventRecord(ev[1], st));
     if (!debug) {
         ShadeArgs sa{};
-        sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->sq; sa.grid = h->grid;
+        sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->fm.sq; sa.grid = h->grid;
         sa.surf64 = h->d_surf; sa.light64 = h->d_light64;
-        sa.accum = h->d_accum; sa.npix = pixels; sa.counters = h->d_counters;
+        sa.accum = h->fm.d_accum; sa.npix = pixels; sa.counters = h->d_counters;
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
         sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
-        sa.deferred = h->d_deferred; sa.deferred_count = h->d_qcounts + 4;
+        sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + 4;
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;
-        sa.exact = h->d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->exact_capacity; sa.work3 = h->d_qcounts + 47;
+        sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
         sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
         rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
-    if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->d_accum, (int64_t)pixels, d_f32, d_u8, st);
+    if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->fm.d_accum, (int64_t)pixels, d_f32, d_u8, st);
     HIP_TRY(h, hipGetLastError());
-    HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : res->c, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : h->host_counters, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipEventRecord(ev[3], st));  // after the counters have landed: waiting for it is enough
     if (enqueue_only) {
-        if (!debug && (d_f32 || d_u8)) h->accum_zero_prefix = zero_before;  // stream order: later bands run after this resolve
+        if (!debug && (d_f32 || d_u8)) h->fm.accum_zero_prefix = zero_before;  // stream order: later bands run after this resolve
         return RT_OK;
     }
     HIP_TRY(h, hipStreamSynchronize(st));
+    std::memcpy(res->c, h->host_counters, sizeof(res->c));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, ev[0], ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, ev[1], ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, ev[2], ev[3]));
-    if (!debug && (d_f32 || d_u8)) h->accum_zero_prefix = zero_before;
+    if (!debug && (d_f32 || d_u8)) h->fm.accum_zero_prefix = zero_before;
     return RT_OK;
 }
 
@@ -357,7 +438,7 @@ int collect_oldest(rt_handle* h) {
     HIP_TRY(h, hipEventElapsedTime(&t1, e.ev[1], e.ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
-    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->exact_capacity) h->async_overflow = true;
+    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->fm.exact_capacity) h->async_overflow = true;
     add_band_stats(h, h->async_sum, e.counters, t0, t1, t2, e.rows);
     h->async_sum.ms_total += all;
     return RT_OK;
@@ -378,12 +459,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     rt_stats s{};
     s.rows_rendered = rows.size();
     if (rows.empty()) { if (stats) *stats = s; return RT_OK; }
-    if (rows.size() > h->row_y_cap) {
-        if (h->d_row_y) (void)hipFree(h->d_row_y);
-        h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
-        HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
-        h->row_y_cap = rows.size();
-    }
+    { int rc0 = ensure_rows(h, rows.size()); if (rc0 != RT_OK) return rc0; }
     const size_t W = (size_t)p->width;
     size_t band_rows = std::max<size_t>(1, std::min(rows.size(), h->max_band_pixels / W));
     int rc = ensure_band_capacity(h, band_rows * W);
@@ -391,22 +467,21 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
 
     hipEvent_t e_begin = h->ev[4];
     HIP_TRY(h, hipEventRecord(e_begin, st));
-    hipEvent_t e_end;
-    HIP_TRY(h, hipEventCreate(&e_end));
+    hipEvent_t e_end = h->ev[5];
     size_t r0 = 0;
     while (r0 < rows.size()) {
         size_t n = std::min(band_rows, rows.size() - r0);
         BandResult br{};
         rc = run_band(h, p, rows.data() + r0, (int)n, d_f32 ? d_f32 + r0 * W * 3 : nullptr,
                       d_u8 ? d_u8 + r0 * W * 3 : nullptr, st, false, &br);
-        if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
-        if (br.c[CNT_EXACT] > h->exact_capacity && !br.c[CNT_OVERFLOW_RAY] && !br.c[CNT_OVERFLOW_SHADE]) {
+        if (rc != RT_OK) return rc;
+        if (br.c[CNT_EXACT] > h->fm.exact_capacity && !br.c[CNT_OVERFLOW_RAY] && !br.c[CNT_OVERFLOW_SHADE]) {
             // more (hit, light) pairs needed their own sphere in float64 than the list holds (a camera inside a glass
             // ball): the counter says how many; rebuild the arena with a list of that size and render the band again
             h->exact_want = (size_t)br.c[CNT_EXACT] + (size_t)br.c[CNT_EXACT] / 4 + 1024;
-            if (h->exact_want > 0x7FFFFFFFu) { (void)hipEventDestroy(e_end); return fail(h, RT_ERR_QUEUE, "float64 pair list beyond 2^31 entries"); }
-            rc = ensure_band_capacity(h, h->band_capacity);
-            if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+            if (h->exact_want > 0x7FFFFFFFu) return fail(h, RT_ERR_QUEUE, "float64 pair list beyond 2^31 entries");
+            rc = ensure_band_capacity(h, h->fm.band_capacity);
+            if (rc != RT_OK) return rc;
             continue;
         }
         if (br.c[CNT_OVERFLOW_RAY] || br.c[CNT_OVERFLOW_SHADE]) {
@@ -415,22 +490,21 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
                 // counted, not written): enlarge the arena to what this band needs and render it again in one piece.
                 // The arena stays that large, so the following frames of the scene do not pay for the discovery again
                 // (a deep ray tree over a 4K band needs a few GB out of 288).
-                const size_t slots = (size_t)h->sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE];
+                const size_t slots = (size_t)h->fm.sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE];
                 const size_t need = (slots + slots / 8 + kShadeFactor - 1) / kShadeFactor;
-                if (need <= kMaxArenaPixels && need > h->band_capacity) {
+                if (need <= kMaxArenaPixels && need > h->fm.band_capacity) {
                     rc = ensure_band_capacity(h, need);
-                    if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+                    if (rc != RT_OK) return rc;
                     continue;
                 }
             }
             if (n == 1) {
                 // a single row outgrew the queues: enlarge them (the ray tree can double per level)
-                if (h->band_capacity * 2 > kMaxArenaPixels) {
-                    (void)hipEventDestroy(e_end);
+                if (h->fm.band_capacity * 2 > kMaxArenaPixels) {
                     return fail(h, RT_ERR_QUEUE, "ray tree of a single row exceeds the largest queue capacity");
                 }
-                rc = ensure_band_capacity(h, h->band_capacity * 2);
-                if (rc != RT_OK) { (void)hipEventDestroy(e_end); return rc; }
+                rc = ensure_band_capacity(h, h->fm.band_capacity * 2);
+                if (rc != RT_OK) return rc;
                 continue;
             }
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
@@ -443,7 +517,6 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     HIP_TRY(h, hipEventSynchronize(e_end));
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, e_begin, e_end));
-    (void)hipEventDestroy(e_end);
     s.ms_total = ms;
     if (stats) *stats = s;
     return RT_OK;
@@ -555,6 +628,18 @@ int rt_create(int device, rt_handle** out) {
     bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts) == hipSuccess;
     if (ok) h->d_qcounts = (uint32_t*)(h->d_counters + CNT_N);
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&h->host_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&h->host_rows, sizeof(int32_t) * kHostRows) == hipSuccess;
+    if (ok) h->host_rows_cap = kHostRows;
+    // this device's copy of the static scratch array (each GPU has its own, at its own address)
+    if (ok && device < 64) {
+        if (!g_scratch_ptr[device]) {
+            void* ptr = nullptr;
+            ok = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) == hipSuccess && ptr != nullptr;
+            if (ok) g_scratch_ptr[device] = ptr;
+        }
+        h->scratch = g_scratch_ptr[device];
+    }
     if (!ok) { rt_destroy(h); return RT_ERR_DEVICE; }
     *out = h;
     return RT_OK;
@@ -570,10 +655,12 @@ void rt_destroy(rt_handle* h) {
     }
     free_frame_buffers(h);
     for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_special, (void*)h->d_counters,
-                    (void*)h->stack_mem, (void*)h->d_grid_mem, (void*)h->d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
+                    (void*)h->fm.stack_mem, (void*)h->d_grid_mem, (void*)h->fm.d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->host_counters) (void)hipHostFree(h->host_counters);
+    if (h->host_rows) (void)hipHostFree(h->host_rows);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -783,16 +870,13 @@ int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32
     // anything that reallocates device memory waits for the frames in flight first
     const size_t need_px = std::max(pixels, (primary_slots((size_t)p->width, rows.size()) * 2 + kShadeFactor - 1) / kShadeFactor);
     const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
-    if (rows.size() > h->row_y_cap || need_px > h->band_capacity || (h->L > 0 ? h->L : 1) > h->arena_lights ||
-        (need_rays && !h->arena_has_rays)) {
+    if (rows.size() > h->fm.row_y_cap || rows.size() > h->host_rows_cap || need_px > h->fm.band_capacity ||
+        (h->L > 0 ? h->L : 1) > h->fm.arena_lights || (need_rays && !h->fm.arena_has_rays)) {
         rc = drain(h);
         if (rc != RT_OK) return rc;
-        if (rows.size() > h->row_y_cap) {
-            if (h->d_row_y) (void)hipFree(h->d_row_y);
-            h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
-            HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
-            h->row_y_cap = rows.size();
-        }
+        HIP_TRY(h, hipStreamSynchronize(st));
+        rc = ensure_rows(h, rows.size());
+        if (rc != RT_OK) return rc;
     }
     if (h->ring_count == kAsyncDepth) { rc = collect_oldest(h); if (rc != RT_OK) return rc; }
     rc = ensure_band_capacity(h, need_px);  // no-op unless drained above (or the first frame)
@@ -837,6 +921,54 @@ int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32,
     return render_impl(h, p, (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, stats);
 }
 
+int rt_render_device_noalloc(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8, void* stream, rt_stats* stats) {
+    if (!h) return RT_ERR_INVALID;
+    if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render_device_noalloc before rt_set_scene");
+    int rc = validate_params(h, p);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(h, hipSetDevice(h->device));
+    if (!h->scratch) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: no scratch array on this device");
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    rc = drain(h);
+    if (rc != RT_OK) return rc;
+    const size_t n_rows = (size_t)rt_rows_selected(p), W = (size_t)p->width;
+    const size_t pixels = n_rows * W;
+    if (pixels > (size_t)RT_NOALLOC_MAX_PIXELS)
+        return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: " + std::to_string(pixels) + " pixels selected, the limit is " +
+                                           std::to_string((size_t)RT_NOALLOC_MAX_PIXELS) + " (RT_NOALLOC_MAX_PIXELS): use rt_render_device");
+    if (n_rows > h->host_rows_cap) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: more rows than the row staging buffer holds");
+    if (pixels == 0) { if (stats) *stats = rt_stats{}; return RT_OK; }
+    // lay the band's queues out in the scratch array: row list first, then the queues, the rest is the ray tree's stack
+    const int lights = h->L > 0 ? h->L : 1;
+    const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
+    const size_t band_px = std::max(pixels, (primary_slots(W, n_rows) * 2 + kShadeFactor - 1) / kShadeFactor);
+    const BandLayout b = band_layout(band_px, lights, need_rays, 0, 0);
+    const size_t rows_bytes = al256(n_rows * sizeof(int32_t));
+    if (rows_bytes + b.bytes > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+        return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: the queues of this frame need " + std::to_string(rows_bytes + b.bytes) +
+                                           " bytes, the static scratch holds " + std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES) +
+                                           ": use rt_render_device");
+    const FrameMem saved = h->fm;
+    const size_t exact_want_saved = h->exact_want;
+    h->exact_want = 0;
+    h->fm = FrameMem{};
+    h->rows_on_device.clear();
+    h->no_alloc = true;
+    char* base = (char*)h->scratch;
+    h->fm.d_row_y = (int32_t*)base; h->fm.row_y_cap = n_rows;
+    char* end = carve_band(h, base + rows_bytes, b, band_px, lights, need_rays);
+    point_tail_stack(h, end, (size_t)((char*)h->scratch + (size_t)RT_NOALLOC_SCRATCH_BYTES - end) / 68);
+    const size_t max_band_saved = h->max_band_pixels;
+    h->max_band_pixels = std::max(h->max_band_pixels, pixels);   // one band: the layout above is for the whole selection
+    rc = render_impl(h, p, (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, stats);
+    h->max_band_pixels = max_band_saved;
+    h->no_alloc = false;
+    h->exact_want = exact_want_saved;
+    h->fm = saved;                 // the handle's own arena (if any) serves the other entry points again
+    h->rows_on_device.clear();
+    return rc;
+}
+
 int rt_render(rt_handle* h, const rt_render_params* p, float* host_rgb_f32, uint8_t* host_rgb_u8, rt_stats* stats) {
     if (!h) return RT_ERR_INVALID;
     if (!h->has_scene) return fail(h, RT_ERR_NO_SCENE, "rt_render before rt_set_scene");
@@ -874,12 +1006,8 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
     const size_t pixels = rows.size() * (size_t)p->width;
     if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "debug probe is limited to one band");
     { int rc0 = drain(h); if (rc0 != RT_OK) return rc0; }
-    if (rows.size() > h->row_y_cap) {
-        if (h->d_row_y) (void)hipFree(h->d_row_y);
-        h->d_row_y = nullptr; h->row_y_cap = 0; h->rows_on_device.clear();
-        HIP_TRY(h, hipMalloc(&h->d_row_y, sizeof(int32_t) * rows.size()));
-        h->row_y_cap = rows.size();
-    }
+    rc = ensure_rows(h, rows.size());
+    if (rc != RT_OK) return rc;
     rc = ensure_band_capacity(h, pixels);
     if (rc != RT_OK) return rc;
     // debug arrays: one allocation, freed with the handle or on the next probe

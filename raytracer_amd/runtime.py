@@ -17,7 +17,7 @@ from . import packing
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_amd.so")
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_render", "rt_render_device",
-           "rt_render_enqueue", "rt_render_wait", "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
+           "rt_render_device_noalloc", "rt_render_enqueue", "rt_render_wait", "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
 
 HF_CBATCH_POS, HF_CDOT_POS, HF_BOX_OUTSIDE, HF_NO_OWN = 1, 2, 4, 8
 
@@ -53,6 +53,8 @@ def load_library():
     L.rt_render.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, C.POINTER(packing.RtStats)]
     L.rt_render_device.restype = C.c_int
     L.rt_render_device.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp, C.POINTER(packing.RtStats)]
+    L.rt_render_device_noalloc.restype = C.c_int
+    L.rt_render_device_noalloc.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp, C.POINTER(packing.RtStats)]
     L.rt_render_enqueue.restype = C.c_int
     L.rt_render_enqueue.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp]
     L.rt_render_wait.restype = C.c_int
@@ -136,6 +138,16 @@ class Renderer:
         st = packing.RtStats()
         self._check(self._lib.rt_render_device(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None,
                                                stream or None, C.byref(st)))
+        return _stats_dict(st)
+
+    def render_rows_device_noalloc(self, width, height, dev_f32_ptr, dev_u8_ptr, *, stream=None, seed=0, row_begin=0,
+                                   row_end=None, stripe_rows=1, stripe_count=1, stripe_index=0, flags=0):
+        """``render_rows_device`` without any device allocation: the queues live in the library's static scratch array
+        (at most ``RT_NOALLOC_MAX_PIXELS`` pixels per call; calls that overlap on one GPU race)."""
+        p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed, flags)
+        st = packing.RtStats()
+        self._check(self._lib.rt_render_device_noalloc(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None,
+                                                       stream or None, C.byref(st)))
         return _stats_dict(st)
 
     def enqueue_rows_device(self, width, height, dev_f32_ptr, dev_u8_ptr, *, stream=None, seed=0, row_begin=0,
