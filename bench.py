@@ -2,29 +2,36 @@
 """Headline benchmark: Mrays/s (primary + shadow + secondary) on pool.txt at 3840x2160, N=16.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
 
-A step is one full frame of scenes/pool_n16.txt (pool geometry, 16x16 soft-shadow
-grid, max_recursions 10) with the scene already resident on the GPU; the frame is
-split into interleaved row stripes over the ranks and the uint8 tiles are gathered
-to rank 0 over RCCL inside the timed region.  The K timed frames are queued and
-alternate over --pipelines renderer handles (streams) per rank, so consecutive
-frames overlap at their ends.  The total frame is fixed, so scaling
-is strong.  Rank 0 prints ONE JSON line.
+With --gpus N > 1 and no launcher in the environment the script starts its N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`, one rank per GPU over RCCL) before
+anything touches the GPU, relays rank 0's JSON line and exits with the launcher's status; started by a
+launcher it checks that WORLD_SIZE equals --gpus and refuses a mismatch.
+
+A step is one full frame of scenes/pool_n16.txt (pool geometry, 16x16 soft-shadow grid, max_recursions 10)
+with the scene already resident on the GPU, delivered as the uint8 frame in (pinned) host memory on rank 0 --
+what the caller of the reference's render() ends up with (ray_tracer.py:436-439).  The frame is split into
+interleaved row stripes over the ranks, the uint8 tiles are gathered to rank 0 over RCCL, and the copy to
+the host runs on a stream of its own behind the following frames' kernels; all of it is inside the timed
+region.  The K timed frames are queued and alternate over --pipelines renderer handles (streams) per rank,
+so consecutive frames overlap at their ends.  The total frame is fixed, so scaling is strong.  Rank 0 prints
+ONE JSON line.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CU x 2.4 GHz x 256 flop/clk/CU, packed FMA)
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # MI355X FP32 vector peak (256 CU x 4 SIMD x 2.4 GHz x 64 flop/clk/SIMD: one packed FMA per 4 cycles)
 
 WORKLOADS = {
     "pool_n16_4k": ("pool_n16", 3840, 2160),
@@ -33,6 +40,17 @@ WORKLOADS = {
     "v7_1080p": ("transparency_v7", 1920, 1080),
     "synthetic_4k": ("synthetic_10k_1k", 3840, 2160),
 }
+
+
+def kernel_source_hash():
+    """Identifies the kernel sources a counter summary under profiles/ was collected on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "raytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(scene_name, width, height, target_seconds=12.0):
@@ -69,6 +87,20 @@ def cpu_baseline(scene_name, width, height, target_seconds=12.0):
             "sample": f"{n} pixels of {scene_name} {width}x{height} ({rays} rays, {dt:.1f} s, float64, OpenMP)"}
 
 
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start the N ranks as children of this process (which has not touched the
+    GPU) and pass rank 0's output through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,9 +112,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true",
                     help="skip the RT_FLAG_NO_CULL frames after the timed region (profiling runs: keeps per-kernel averages clean)")
+    ap.add_argument("--no-device-resident", action="store_true",
+                    help="skip the second timed loop that leaves the frames on the device (profiling runs)")
     ap.add_argument("--no-cull", action="store_true",
                     help="brute force: every shadow ray against every surface (RT_FLAG_NO_CULL), for A/B numbers")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    launched = "WORLD_SIZE" in os.environ
+    if not launched and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to report a mismatched run",
+                  file=sys.stderr)
+        sys.exit(2)
 
     import torch
     import torch.distributed as dist
@@ -90,15 +138,16 @@ def main():
     from raytracer_amd import runtime
     from raytracer_amd.distributed import DistributedRenderer
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # RT_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a box with fewer GPUs than ranks -- the ranks share the
     # visible GPUs and gather over gloo (RCCL refuses two ranks on one device); the numbers mean nothing, the code path
     # (stripes, gather, assembly, reductions, the JSON line) is the real one
     rehearse = os.environ.get("RT_BENCH_REHEARSE") == "1"
     if rehearse:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    elif world > 1 and torch.cuda.device_count() < world:
+        if rank == 0:
+            print(f"bench.py: --gpus {world} but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -109,14 +158,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     scene_name, W, H = WORKLOADS[args.workload]
     scene = R.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".txt"))
     renderer = runtime.Renderer(local_rank)
     renderer.set_scene(scene)
-    dr = DistributedRenderer(renderer, W, H, flags=2 if args.no_cull else 0, pipelines=args.pipelines)
+    flags = 2 if args.no_cull else 0
+    dr = DistributedRenderer(renderer, W, H, flags=flags, pipelines=args.pipelines, to_host=True)
 
     def barrier():
         if world > 1:
@@ -127,25 +175,51 @@ def main():
         if rehearse:
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
+    def timed(d, first_seed):
+        """K queued frames between two barriers; returns (seconds, summed stats of this rank)."""
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            d.enqueue(seed=first_seed + i)
+        try:
+            st = d.finish()
+        except runtime.RtError as e:
+            if e.code != -5:
+                raise
+            # a queued frame outgrew the ray / shade queues (they cannot grow while frames are in flight): size them
+            # with one synchronous frame per pipeline, which grows them, and time the K frames again
+            for k in range(len(d.lanes)):
+                d.render(seed=first_seed, pipeline=k)
+            return timed(d, first_seed)
+        barrier()
+        return time.perf_counter() - t0, st
+
     note("renderer ready")
     isolated = None   # kernel times of a frame rendered alone (warm-up frames run one at a time on one stream)
     for i in range(args.warmup):
         _, isolated = dr.render(seed=i)
     dr.prepare()      # every pipeline has rendered once before the clock starts
+    if isolated is None:
+        _, isolated = dr.render(seed=0)
     note("warm-up done")
-    barrier()
-    t0 = time.perf_counter()
-    # the K frames are queued back to back (render, gather, assembly: no host round trip between frames) and
-    # collected once; every kernel still carries its own HIP events, read when the frames are collected
-    for i in range(args.steps):
-        dr.enqueue(seed=1000 + i)
-    st = dr.finish()
+    # ---- the timed region: K frames, each delivered to host memory on rank 0 ---------------------------------
+    dt, st = timed(dr, 1000)
     note("timed frames done")
     rays = st["total_rays"]
     wave_light = list(st["wave_light"])
-    ms_shade, flop_shade, ms_trace, ms_resolve = st["ms_shade"], st["flop_shade"], st["ms_trace"], st["ms_resolve"]
-    barrier()
-    dt = time.perf_counter() - t0
+    ms_shade, ms_main, flop_shade, ms_trace, ms_resolve = st["ms_shade"], st["ms_shade_main"], st["flop_shade"], st["ms_trace"], st["ms_resolve"]
+    samples = st["shadow_samples"]
+    host_ok = None
+    if rank == 0:
+        hf = dr.host_frame()
+        host_ok = bool(hf is not None and hf.shape == (H, W, 3) and int(hf.max()) > 0)
+
+    # ---- the same K frames left on the device (no copy to the host): reported beside the headline ------------
+    dt_dev = None
+    if not args.no_device_resident:
+        dr.deliver = False
+        dt_dev, _ = timed(dr, 3000)
+        dr.deliver = True
 
     # the same frame with RT_FLAG_NO_CULL (every shadow ray against every surface): what the straightforward
     # kernel reaches of the vector peak; outside the timed region, rank 0 of a single-GPU run only
@@ -157,28 +231,40 @@ def main():
         for i in range(2):
             _, stb = drb.render(seed=2000 + i)
             bms += stb["ms_shade"]; bfl += stb["flop_shade"]
-        brute = {"shade_ms_per_frame": bms / 2, "achieved": (bfl / 1e12) / (bms / 1e3), "unit": "TFLOP/s",
-                 "frac": (bfl / 1e12) / (bms / 1e3) / FP32_VECTOR_PEAK_TFLOPS}
+        brute = {"shade_ms_per_frame": bms / 2, "algorithmic_tflops": (bfl / 1e12) / (bms / 1e3),
+                 "algorithmic_over_peak": (bfl / 1e12) / (bms / 1e3) / FP32_VECTOR_PEAK_TFLOPS}
 
     if world > 1:
-        t = torch.tensor([dt, float(rays), ms_shade, flop_shade], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+        t = torch.tensor([dt, float(rays), float(samples), dt_dev or 0.0, float(st["shadow_rays"])], dtype=torch.float64,
+                         device="cpu" if rehearse else "cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0]); rays_total = float(tsum[1])
+        dt = float(tmax[0]); rays_total = float(tsum[1]); samples_total = float(tsum[2])
+        dt_dev = float(tmax[3]) if dt_dev is not None else None
+        shadow_total = float(tsum[4])
     else:
-        rays_total = float(rays)
+        rays_total = float(rays); samples_total = float(samples); shadow_total = float(st["shadow_rays"])
 
     if rank == 0:
         steps = max(args.steps, 1)
-        # dominant kernel = the shading / soft-shadow kernel (rank 0's launches, HIP-event timed on its stream)
-        achieved = (flop_shade / 1e12) / (ms_shade / 1e3) if ms_shade > 0 else 0.0
-        traffic = None
+        # ---- roofline of the dominant kernel ------------------------------------------------------------------
+        # executed FP32 flop per launch: rocprofv3 per-class VALU counters of this build (tools/profile.sh,
+        # profiles/shade_roofline.json); time: the same launch measured live with HIP events on its own stream,
+        # running alone (the last warm-up frame) -- in the timed region two pipelines overlap and a launch's
+        # event-to-event time includes time shared with the other stream's kernels
         pmc = {}
-        tpath = os.path.join(ROOT, "profiles", "shade_hbm_traffic.json")
-        if world == 1 and args.workload == "pool_n16_4k" and not args.no_cull and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "shade_roofline.json")
+        if os.path.exists(tpath):
             with open(tpath) as f:
-                pmc = json.load(f)
-            traffic = pmc.get("hbm_bytes_per_launch")
+                pmc = json.load(f).get(args.workload, {})
+        iso_ms = isolated["ms_shade_main"] if isolated else 0.0
+        timed_ms = ms_main / steps
+        executed = pmc.get("executed_fp32_flop_per_launch")
+        achieved = (executed / 1e12) / (iso_ms / 1e3) if executed and iso_ms > 0 and world == 1 and not args.no_cull else None
+        algorithmic_iso = (isolated["flop_shade"] / 1e12) / (isolated["ms_shade"] / 1e3) if isolated and isolated["ms_shade"] > 0 else None
+        desc = f"scenes/{scene_name}.txt at {W}x{H}"
+        if args.workload == "pool_n16_4k":
+            desc += " (pool geometry, 16x16 soft-shadow grid, max_recursions 10)"
         out = {
             "metric": "Mrays/s (primary+shadow+secondary) at 3840x2160 pool.txt; frame time ms",
             "value": rays_total / dt / 1e6,
@@ -190,36 +276,45 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"scenes/{scene_name}.txt at {W}x{H} (pool geometry, 16x16 soft-shadow grid, "
-                                   "max_recursions 10)" if args.workload == "pool_n16_4k"
-                       else f"scenes/{scene_name}.txt at {W}x{H}",
-                       "rays_per_frame": rays_total / steps, "partition": f"row stripes x{world}, uint8 gather to rank 0",
+            "config": {"workload": desc,
+                       "rays_per_frame": rays_total / steps,
+                       "rays_definition": "the reference's count: primary + traced secondary + N*N shadow rays per (shaded hit, "
+                                          "light) (1 for single-ray lights); shadow_samples_generated_per_frame is what the "
+                                          "kernels really sampled after deciding whole (wavefront, light) pairs and sample tiles without sampling",
+                       "shadow_samples_generated_per_frame": samples_total / steps,
+                       "partition": f"row stripes x{world}, uint8 gather to rank 0",
+                       "delivery": "uint8 frame in pinned host memory on rank 0, copy on its own stream inside the timed region",
+                       "host_frame_checked": host_ok,
                        "pipelines": args.pipelines,
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},
+            "device_resident": None if dt_dev is None else {
+                "ms_per_step": dt_dev / steps * 1e3, "value": rays_total / dt_dev / 1e6, "unit": "Mrays/s",
+                "note": "the same K frames with the uint8 frame left on rank 0's device (no copy to the host)"},
+            "value_generated_samples_only": (rays_total - shadow_total + samples_total) / dt / 1e6,
             "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "float64_pairs"], wave_light)),
-            "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "resolve": ms_resolve / steps},
+            "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "shade_main_kernel": timed_ms,
+                                          "resolve": ms_resolve / steps,
+                                          "isolated": None if not isolated else {k: isolated[k] for k in ("ms_trace", "ms_shade", "ms_shade_main", "ms_resolve")}},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "k_shade_fast + k_shade_deferred (Phong + in-register N x N soft shadows), FP32 "
-                                   "vector ALU; no dense contraction, so neither HBM nor MFMA binds it",
-                         "note": "achieved = algorithmic flop (per-ray test costs fixed by convention) / measured kernel "
-                                 "time; it can exceed the peak because the kernel reaches the same result without "
-                                 "performing that arithmetic (per-light surface classification, 3-FMA linear tests, skipped sample "
-                                 "tiles); brute_force = the same frame and flop count with every ray tested against every "
-                                 "surface (RT_FLAG_NO_CULL). With pipelines > 1 the timed frames alternate over that many "
-                                 "streams and their kernels overlap, so the HIP-event duration of a launch (achieved, "
-                                 "kernel_ms_per_frame_rank0) includes time shared with the other stream's kernels; isolated = "
-                                 "the same launch of the last warm-up frame, which runs alone. "
-                                 "valu_issue = measured VALU instructions per SIMD cycle of k_shade_fast (rocprofv3 PMC, "
-                                 "profiles/) against the v_fma_f32 issue ceiling measured on this chip.",
-                         "isolated": None if not isolated or isolated["ms_shade"] <= 0 else {
-                             "shade_ms_per_frame": isolated["ms_shade"],
-                             "achieved": (isolated["flop_shade"] / 1e12) / (isolated["ms_shade"] / 1e3), "unit": "TFLOP/s",
-                             "frac": (isolated["flop_shade"] / 1e12) / (isolated["ms_shade"] / 1e3) / FP32_VECTOR_PEAK_TFLOPS},
+                         "frac": None if achieved is None else achieved / FP32_VECTOR_PEAK_TFLOPS,
+                         "traffic": pmc.get("hbm_bytes_per_launch"),
+                         "kernel": pmc.get("kernel", "k_shade_fast") + " (Phong + in-register N x N soft shadows), FP32 vector ALU; "
+                                   "no dense contraction, so neither HBM nor MFMA binds it",
+                         "executed_fp32_flop_per_launch": executed,
+                         "launch_ms_isolated_live": iso_ms, "launch_ms_in_timed_region_overlapped": timed_ms,
+                         "launch_ms_under_pmc": pmc.get("ms_under_pmc"),
+                         "counters": pmc.get("counters"),
+                         "pmc_profile": pmc.get("profile"), "pmc_kernel_source_hash": pmc.get("kernel_source_hash"),
+                         "pmc_matches_this_build": (pmc.get("kernel_source_hash") == kernel_source_hash()) if pmc else None,
+                         "valu_issue": pmc.get("valu_issue"),
+                         "algorithmic_over_peak": None if algorithmic_iso is None else {
+                             "tflops": algorithmic_iso, "ratio": algorithmic_iso / FP32_VECTOR_PEAK_TFLOPS,
+                             "note": "reference-equivalent flop (every N*N shadow ray against every surface, per-test costs fixed "
+                                     "by convention) / isolated shading time: a speed-up over brute force, NOT a roofline fraction"},
                          "brute_force": brute,
-                         "valu_issue": {"cycles_per_valu_inst_per_simd": pmc.get("cycles_per_valu_inst_per_simd"),
-                                        "ceiling_cycles_v_fma_f32": 4.0,
-                                        "effective_clock_ghz": pmc.get("effective_clock_ghz")} if pmc else None},
+                         "note": "achieved = FP32 flop the kernel EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 "
+                                 "x 64 lanes, FMA = 2; counters collected on this build, see pmc_*) / the launch's duration measured "
+                                 "live with HIP events on its own stream, running alone"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene_name, W, H)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+#define RT_ABI_VERSION 2
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -132,6 +132,12 @@ typedef struct rt_stats {
                                  [7] not a wavefront class: (hit, light) pairs whose own-sphere samples were
                                      evaluated in float64 (hits on a sphere with c > 0; lights lying on a surface:
                                      raytracer_amd/csrc/rt_exact.h) */
+    double ms_shade_main;     /* of ms_shade: the dominant kernel alone (k_shade_fast; k_shade_general for scenes of more
+                                 than 16 surfaces), HIP events around that one launch                              */
+    uint64_t shadow_samples;  /* shadow-ray samples the kernels really generated and tested, counted per lane that
+                                 holds a hit: shadow_rays above is the reference's count (N*N per hit and light),
+                                 this is what is left of it after whole (wavefront, light) pairs and whole sample
+                                 tiles were decided without sampling                                               */
 } rt_stats;
 
 typedef struct rt_handle rt_handle;

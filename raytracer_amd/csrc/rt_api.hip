@@ -124,9 +124,9 @@ struct rt_handle {
     float* d_out_f32 = nullptr;
     uint8_t* d_out_u8 = nullptr;
     size_t out_cap = 0;              // values
-    hipEvent_t ev[6]{};              // [0..3] band stages, [4], [5] begin / end of a synchronous call
+    hipEvent_t ev[7]{};              // [0..3] band stages, [4] behind the main shading launch, [5], [6] begin / end of a synchronous call
     // frames enqueued by rt_render_enqueue and not yet collected
-    struct Pending { hipEvent_t ev[4]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
+    struct Pending { hipEvent_t ev[5]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
     Pending ring[kAsyncDepth];
     bool ring_ready = false;
     int ring_head = 0, ring_count = 0;   // oldest entry, entries in flight
@@ -255,7 +255,7 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
         if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) rows.push_back(y);
 }
 
-struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_resolve; };
+struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_shade_main, ms_resolve; };
 
 void point_tail_stack(rt_handle* h, void* mem, size_t slots) {
     char* p = (char*)mem;
@@ -395,7 +395,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.special = h->d_special;
         sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
         sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
-        rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st);
+        rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st, ev[4]);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->fm.d_accum, (int64_t)pixels, d_f32, d_u8, st);
@@ -410,15 +410,18 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     std::memcpy(res->c, h->host_counters, sizeof(res->c));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, ev[0], ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, ev[1], ev[2]));
+    res->ms_shade_main = 0.f;
+    if (!debug) HIP_TRY(h, hipEventElapsedTime(&res->ms_shade_main, ev[1], ev[4]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, ev[2], ev[3]));
     if (!debug && (d_f32 || d_u8)) h->fm.accum_zero_prefix = zero_before;
     return RT_OK;
 }
 
-void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, float ms_trace, float ms_shade, float ms_resolve, size_t rows) {
+void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, float ms_trace, float ms_shade, float ms_shade_main, float ms_resolve, size_t rows) {
     s.primary_rays += c[CNT_PRIMARY]; s.secondary_rays += c[CNT_SECONDARY];
     s.depth_cut += c[CNT_DEPTH_CUT]; s.shaded_points += c[CNT_SHADED];
-    s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_resolve += ms_resolve;
+    s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_shade_main += ms_shade_main; s.ms_resolve += ms_resolve;
+    s.shadow_samples += c[CNT_SAMPLES];
     for (int k = 0; k < 7; ++k) s.wave_light[k] += c[CNT_WL_NONE + k];
     s.wave_light[7] += c[CNT_EXACT];
     s.bands += 1;
@@ -433,13 +436,14 @@ int collect_oldest(rt_handle* h) {
     h->ring_head = (h->ring_head + 1) % kAsyncDepth;
     h->ring_count -= 1;
     HIP_TRY(h, hipEventSynchronize(e.ev[3]));
-    float t0 = 0, t1 = 0, t2 = 0, all = 0;
+    float t0 = 0, t1 = 0, t1m = 0, t2 = 0, all = 0;
     HIP_TRY(h, hipEventElapsedTime(&t0, e.ev[0], e.ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&t1, e.ev[1], e.ev[2]));
+    HIP_TRY(h, hipEventElapsedTime(&t1m, e.ev[1], e.ev[4]));
     HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
     if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->fm.exact_capacity) h->async_overflow = true;
-    add_band_stats(h, h->async_sum, e.counters, t0, t1, t2, e.rows);
+    add_band_stats(h, h->async_sum, e.counters, t0, t1, t1m, t2, e.rows);
     h->async_sum.ms_total += all;
     return RT_OK;
 }
@@ -465,9 +469,9 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
     int rc = ensure_band_capacity(h, band_rows * W);
     if (rc != RT_OK) return rc;
 
-    hipEvent_t e_begin = h->ev[4];
+    hipEvent_t e_begin = h->ev[5];
     HIP_TRY(h, hipEventRecord(e_begin, st));
-    hipEvent_t e_end = h->ev[5];
+    hipEvent_t e_end = h->ev[6];
     size_t r0 = 0;
     while (r0 < rows.size()) {
         size_t n = std::min(band_rows, rows.size() - r0);
@@ -510,7 +514,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
         }
-        add_band_stats(h, s, br.c, br.ms_trace, br.ms_shade, br.ms_resolve, 0);
+        add_band_stats(h, s, br.c, br.ms_trace, br.ms_shade, br.ms_shade_main, br.ms_resolve, 0);
         r0 += n;
     }
     HIP_TRY(h, hipEventRecord(e_end, st));

@@ -126,6 +126,7 @@ enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_R
        // with 1..4 linear tests, generic loop (some lane needs it / more than 4 candidates), single-ray path
        CNT_WL_NONE, CNT_WL_K1, CNT_WL_K2, CNT_WL_K3, CNT_WL_K4, CNT_WL_GENERIC, CNT_WL_POINT,
        CNT_EXACT,  // (hit, light) pairs evaluated by k_shade_exact
+       CNT_SAMPLES,  // shadow-ray samples generated and tested by the shading kernels (lanes holding a hit x samples)
        CNT_N };
 
 struct FrameParams {
@@ -212,6 +213,7 @@ struct ShadeArgs {
     size_t npix;
     unsigned long long* counters;
 };
-void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s);
+// after_main (may be null) is recorded behind the first, dominant launch
+void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s, hipEvent_t after_main);
 
 void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s);

@@ -331,6 +331,8 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
     return f;
 }
 
+__device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio);
+
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
     const int L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
+    unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
 
     for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
         HitRec hr;
@@ -356,7 +359,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         const float inward_limit = -0.2f * own_sf.c.x;   // see k_shade_deferred
         const double* p64 = a.q.p64 + (size_t)(base + lane) * 3;
 
-        f3 color = F3(0.f, 0.f, 0.f);
+        const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
+        // Every light adds (double)(weight * term) -- the same value whichever kernel shades that (hit, light) pair --
+        // and the lights are summed in float64: which pairs a wave defers depends on which hits share the wave, and
+        // with FP32 sums the pixel would carry that in its last FP32 bit (a byte flips when it sits on an integer).
+        double cx = 0.0, cy = 0.0, cz = 0.0;
         for (int l = 0; l < L; ++l) {
             if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
@@ -370,6 +377,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             float ratio;
             if (lt.point_path) {
                 // ---- one ray to the light centre (ray_tracer.py:36-48)
+                n_samples += n_active;
                 const float dist = lc2 * linv;
                 ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags, ~0ull);
                 if (exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
@@ -456,28 +464,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                     }
                 }
                 ratio = reach_mask ? sum * inv_n2 : 1.f;
+                if (reach_mask) n_samples += (unsigned long long)(N * N) * n_active;
             }
             // ---- intensity (ray_tracer.py:105) and Phong terms (:157-170)
-            const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
-            if (inten != 0.f) {
-                const float ndl = fmaxf(0.f, dot(nrm, ldir));
-                const float k2 = 2.f * dot(ldir, nrm);
-                const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
-                const float rv = dot(rdir, view);
-                const float sp = rv > 0.f ? pow_pos(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
-                const float spi = sp * lt.spec;
-                color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
-                color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
-                color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
-            }
+            f3 term = F3(0.f, 0.f, 0.f);
+            phong_add(term, nrm, ldir, view, m, lt, ratio);
+            cx += (double)(hr.wgt.x * term.x); cy += (double)(hr.wgt.y * term.y); cz += (double)(hr.wgt.z * term.z);
         }
         if (active) {
             const uint32_t lp = hr.lpix;
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(hr.wgt.x * color.x));
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(hr.wgt.y * color.y));
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(hr.wgt.z * color.z));
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], cx);
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], cy);
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], cz);
         }
     }
+    if (lane == 0 && n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
 }
 
 
@@ -577,7 +578,7 @@ __device__ __forceinline__ void box_values(const BoxSet& bx, float ur, float vr,
 template <int K, int NB, bool ALL_OPAQUE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
                                                  const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX],
-                                                 const BoxSet& bx) {
+                                                 const BoxSet& bx, uint32_t& n_generated) {
     // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
     // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
     // from the corners; when, for every lane of the wave, either no entry can block anywhere in
@@ -627,6 +628,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                 for (int j0 = J0; j0 < J1; j0 += T2) {
                     const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
                     if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
+                    n_generated += (uint32_t)((i1 - i0) * (j1 - j0));   // (wave-uniform)
                     for (int i = i0; i < i1; ++i) {
                         uint32_t ctr = key + (uint32_t)(i * N + j0) * 0x9E3779B9u;
                         uint32_t mask = 0;
@@ -699,6 +701,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
     // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
     // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
     // work item = one 64-hit chunk with all its lights (splitting a chunk by light was measured slower: the hit is
     // loaded and its accumulators updated once per part, and short items saturate the shared work counter)
     const uint32_t n_items = (count + 63u) >> 6;
@@ -729,8 +732,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
         const bool own_sph_blocks = own_sphere && !(h.flags & HF_CBATCH_POS);
 
         const float pfuzz_hit = 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z));
+        const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
 
-        f3 color = F3(0.f, 0.f, 0.f);
+        double cx = 0.0, cy = 0.0, cz = 0.0;   // lights summed in float64 (see k_shade_general)
         for (int l = 0; l < L; ++l) {
             if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
@@ -933,37 +937,39 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                             }
                         }
                         float sum;
+                        uint32_t n_gen = 0;
                         if (!HAS_BOX || nb == 0) {
                             switch (k) {
-                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
                             }
                         } else {
                             // boxes: linear rows rounded up to 0 / 2 / 4 / 8 (spare rows are inert), boxes to 1 or NBMAX
                             const int kk = k == 0 ? 0 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
                             if (nb == 1) {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
                                 }
                             } else {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
-                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx); break;
+                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
                                 }
                             }
                         }
                         ratio = sum * inv_n2;
+                        n_samples += (unsigned long long)n_gen * n_active;
                     }
                 }
             }
@@ -974,20 +980,23 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                 }
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
-                phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+                f3 term = F3(0.f, 0.f, 0.f);
+                phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+                cx += (double)(h.wgt.x * term.x); cy += (double)(h.wgt.y * term.y); cz += (double)(h.wgt.z * term.z);
             }
         }
-        if (active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
+        if (active && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
             const uint32_t lp = h.lpix;
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(h.wgt.x * color.x));
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(h.wgt.y * color.y));
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(h.wgt.z * color.z));
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], cx);
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], cy);
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], cz);
         }
     }
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 7; ++c)
             if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
+        if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
     }
 }
 
@@ -1218,6 +1227,8 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             __syncthreads();
             ratio = sum * inv_n2;
         }
+        const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
+        if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_SAMPLES], (unsigned long long)(lt.point_path ? 1 : N * N) * n_active);
         f3 color = F3(0.f, 0.f, 0.f);
         phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
         if (wv == 0 && active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
@@ -1444,7 +1455,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
 }
 
 template <int SM>
-static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s) {
+static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s, hipEvent_t after_main) {
     if (a.has_box) {
         if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, true, SM>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_shade_fast<false, true, SM>), g, b, 0, s, a);
@@ -1452,6 +1463,7 @@ static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s) {
         if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, false, SM>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_shade_fast<false, false, SM>), g, b, 0, s, a);
     }
+    if (after_main) (void)hipEventRecord(after_main, s);
     if (a.has_box) {
         if (a.all_opaque) hipLaunchKernelGGL((k_shade_deferred<true, true, SM>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_shade_deferred<true, false, SM>), g, b, 0, s, a);
@@ -1464,15 +1476,16 @@ static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s) {
 // Scenes of up to 8 surfaces use the register-resident kernels at full occupancy, 9..16 surfaces the same kernels
 // with twice the per-surface registers (two waves per SIMD; a deferred item then has 16 bits for the light), larger
 // scenes the any-size kernel.
-void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s) {
+void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s, hipEvent_t after_main) {
     const dim3 g(blocks), b(SHADE_BLOCK);
     const int S = a.fp.n_surfaces;
     if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
+        if (after_main) (void)hipEventRecord(after_main, s);
     } else if (S > SMALL_MAX) {
-        launch_small<16>(a, g, b, s);
+        launch_small<16>(a, g, b, s, after_main);
     } else {
-        launch_small<SMALL_MAX>(a, g, b, s);
+        launch_small<SMALL_MAX>(a, g, b, s, after_main);
     }
     hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
 }

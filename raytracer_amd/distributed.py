@@ -151,11 +151,19 @@ def concurrent_streams(torch, device, n, candidates=12):
 
 
 class _Pipeline:
-    """One renderer handle, its stream and its gather buffers: frames of one pipeline run in order."""
+    """One renderer handle, its stream and its gather buffers: frames of one pipeline run in order.
 
-    def __init__(self, renderer, stream, gatherer):
-        self.r, self.stream, self.g = renderer, stream, gatherer
+    Two buffer sets alternate from frame to frame, so the frame that is being copied to the host (``to_host``) is not
+    the one the next frame of this pipeline renders and gathers into.
+    """
+
+    def __init__(self, renderer, stream, gatherers):
+        self.r, self.stream, self.gs = renderer, stream, gatherers
+        self.g = gatherers[0]
         self.used = False
+        self.count = 0          # frames put on this pipeline
+        self.host = None        # pinned host frames, one per buffer set (rank 0, to_host)
+        self.copied = None      # events: the copy out of buffer set b has finished
 
 
 class DistributedRenderer:
@@ -165,9 +173,13 @@ class DistributedRenderer:
     its own stream, tile and gather buffers, so the first kernels of frame k+1 fill the GPU while the last, long
     work items of frame k drain (two pipelines: 10 % more frames per second on a full 4K frame, 41 % on an eighth
     of it; a third one did not help).  Frame k is complete when ``finish()`` returns.
+
+    ``to_host``: on rank 0 every queued frame is also copied into pinned host memory (``host_frame``), on a copy
+    stream of its own, behind the kernels of the following frames -- the uint8 frame the caller of the reference's
+    ``render()`` ends up with (ray_tracer.py:436-439).
     """
 
-    def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0, pipelines=1):
+    def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0, pipelines=1, to_host=False):
         import torch
 
         from . import runtime
@@ -180,6 +192,7 @@ class DistributedRenderer:
         dev = torch.device("cuda", renderer.device)
         self.device = dev
         self.lanes = []
+        self.to_host = bool(to_host)
         streams = concurrent_streams(torch, dev, pipelines) if pipelines > 1 else [None]
         for i in range(pipelines):
             if i == 0:
@@ -188,19 +201,42 @@ class DistributedRenderer:
                 if renderer._packed is None:
                     raise RuntimeError("DistributedRenderer: upload the scene (set_scene) before asking for pipelines")
                 r = runtime.Renderer(renderer.device).set_scene(renderer._packed)
-            self.lanes.append(_Pipeline(r, streams[i], TileGatherer(width, height, dev, group, stripe_rows)))
+            sets = 2 if to_host else 1
+            self.lanes.append(_Pipeline(r, streams[i], [TileGatherer(width, height, dev, group, stripe_rows) for _ in range(sets)]))
         g = self.lanes[0].g
         self.W, self.H, self.world, self.rank = g.W, g.H, g.world, g.rank
         self.stripe_rows, self.my_rows = g.stripe_rows, g.my_rows
         self.next_lane = 0
+        self.copy_stream = None
+        if self.to_host and self.rank == 0:
+            self.copy_stream = torch.cuda.Stream(device=dev)
+            for lane in self.lanes:
+                lane.host = [torch.empty((self.H, self.W, 3), dtype=torch.uint8).pin_memory() for _ in lane.gs]
+                lane.copied = [torch.cuda.Event() for _ in lane.gs]
+        self.last_host_frame = None
+        self.deliver = True     # set False to leave the following frames on the device (same buffers, no host copy)
 
     def _frame(self, lane, seed, queued):
-        g = lane.g
-        stream = self.torch.cuda.current_stream(self.device).cuda_stream
+        torch = self.torch
+        b = lane.count % len(lane.gs)
+        g = lane.g = lane.gs[b]
+        cur = torch.cuda.current_stream(self.device)
+        if self.copy_stream is not None and lane.count >= len(lane.gs):
+            cur.wait_event(lane.copied[b])      # this buffer set is still the source of an earlier copy
+        lane.count += 1
         call = lane.r.enqueue_rows_device if queued else lane.r.render_rows_device
-        stats = call(self.W, self.H, 0, g.tile.data_ptr(), stream=stream, seed=seed, stripe_rows=self.stripe_rows,
+        stats = call(self.W, self.H, 0, g.tile.data_ptr(), stream=cur.cuda_stream, seed=seed, stripe_rows=self.stripe_rows,
                      stripe_count=self.world, stripe_index=self.rank, flags=self.flags)
-        return g.gather(), stats
+        frame = g.gather()
+        if self.copy_stream is not None and frame is not None and self.deliver:
+            done = torch.cuda.Event()
+            done.record(cur)
+            self.copy_stream.wait_event(done)
+            with torch.cuda.stream(self.copy_stream):
+                lane.host[b][: frame.shape[0]].copy_(frame, non_blocking=True)
+                lane.copied[b].record(self.copy_stream)
+            self.last_host_frame = lane.host[b]
+        return frame, stats
 
     def prepare(self):
         """Render one frame on every pipeline that has not rendered yet (queue allocation, first-launch costs), so
@@ -214,15 +250,19 @@ class DistributedRenderer:
         lane = self.lanes[pipeline]
         lane.used = True
         if lane.stream is None:
-            return self._frame(lane, seed, queued=False)
-        with self.torch.cuda.stream(lane.stream):   # the handle's frames stay on one stream
             out = self._frame(lane, seed, queued=False)
-        lane.stream.synchronize()
+        else:
+            with self.torch.cuda.stream(lane.stream):   # the handle's frames stay on one stream
+                out = self._frame(lane, seed, queued=False)
+            lane.stream.synchronize()
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
         return out
 
     def enqueue(self, seed=0):
-        """Put one frame (render + gather + assembly) on the next pipeline's stream without waiting for it; returns
-        the frame tensor on rank 0 (complete after ``finish()``; overwritten by the frame ``pipelines`` later)."""
+        """Put one frame (render + gather + assembly, and the copy to the host with ``to_host``) on the next pipeline's
+        stream without waiting for it; returns the frame tensor on rank 0 (complete after ``finish()``; overwritten
+        by a later frame of the same pipeline)."""
         lane = self.lanes[self.next_lane]
         lane.used = True
         self.next_lane = (self.next_lane + 1) % len(self.lanes)
@@ -232,15 +272,32 @@ class DistributedRenderer:
             return self._frame(lane, seed, queued=True)[0]
 
     def finish(self):
-        """Wait for every enqueued frame of this rank (kernels, gather, assembly); returns the summed stats dict."""
+        """Wait for every enqueued frame of this rank (kernels, gather, assembly, host copies); returns the summed
+        stats dict.  A frame that outgrew the queues makes this raise ``runtime.RtError`` (code -5) after everything
+        has drained: render that sequence again through ``render()``, which resizes the queues."""
         total = None
+        error = None
         for lane in self.lanes:
-            st = lane.r.wait()
+            try:
+                st = lane.r.wait()
+            except Exception as e:      # keep draining the other pipelines: nothing may stay in flight
+                error = error or e
+                st = None
             if lane.stream is not None:
                 lane.stream.synchronize()
+            if st is None:
+                continue
             if total is None:
                 total = st
             else:
                 for k, v in st.items():
                     total[k] = [a + b for a, b in zip(total[k], v)] if isinstance(v, list) else total[k] + v
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
+        if error is not None:
+            raise error
         return total
+
+    def host_frame(self):
+        """Pinned host copy (numpy view) of the most recently queued frame on rank 0 (valid after ``finish()``)."""
+        return None if self.last_host_frame is None else self.last_host_frame.numpy()

@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-RT_ABI_VERSION = 1
+RT_ABI_VERSION = 2
 RT_SURF_SPHERE, RT_SURF_PLANE, RT_SURF_BOX, RT_SURF_PLANE_RAW = 0, 1, 2, 3
 RT_MAT_STRIDE, RT_LIGHT_STRIDE = 11, 9
 
@@ -47,6 +47,7 @@ class RtStats(C.Structure):
         ("bands", C.c_uint32), ("reserved", C.c_uint32),
         ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
         ("ms_resolve", C.c_double), ("flop_shade", C.c_double), ("wave_light", C.c_uint64 * 8),
+        ("ms_shade_main", C.c_double), ("shadow_samples", C.c_uint64),
     ]
 
     def as_dict(self):

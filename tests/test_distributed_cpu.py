@@ -62,3 +62,16 @@ def test_stripe_helpers():
         rows = sorted(sum((D.rank_rows(100, world, r, 7) for r in range(world)), []))
         assert rows == list(range(100))
     assert D.max_rows_per_rank(27, 2, 4) == 15
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """Started by a launcher whose WORLD_SIZE differs from --gpus, bench.py exits non-zero before touching a GPU
+    (a run reported as N GPUs must have used N ranks)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 2 and "refusing" in out.stderr and "{" not in out.stdout

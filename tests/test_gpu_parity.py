@@ -800,20 +800,16 @@ def test_ground_plane_towards_the_horizon(renderer, oracle, tmp_path):
 
 
 def test_two_rank_bench_rehearsal_on_one_gpu():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on one
-    GPU: both ranks share the device and gather over gloo (RT_BENCH_REHEARSE=1).  Stripes, gather, assembly, the
-    reductions and the JSON line are the code the multi-GPU run executes; the ray count must be the whole frame's."""
-    import socket
+    """`python bench.py --gpus 2` exactly as the driver types it, with no launcher in the command line: the script starts
+    its two ranks itself.  Rehearsed on one GPU: both ranks share the device and gather over gloo
+    (RT_BENCH_REHEARSE=1).  Stripes, gather, assembly, host delivery, the reductions and the JSON line are the code
+    the multi-GPU run executes; the ray count must be the whole frame's."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, RT_BENCH_REHEARSE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RT_BENCH_REHEARSE"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=110)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
@@ -821,6 +817,9 @@ def test_two_rank_bench_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["unit"] == "Mrays/s" and d["scaling"] == "strong"
     assert d["config"]["rays_per_frame"] == 14358303438.0      # both halves of the 4K pool N = 16 frame
     assert d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["host_frame_checked"] is True           # the assembled frame reached pinned host memory
+    assert d["device_resident"]["ms_per_step"] > 0
+    assert 0 < d["config"]["shadow_samples_generated_per_frame"] < d["config"]["rays_per_frame"]
 
 
 def test_mid_size_scene_uses_the_reach_mask(renderer, oracle, tmp_path):

@@ -1,12 +1,17 @@
 #!/usr/bin/env python3
-"""Condense gpurun_out/prof_<tag>/ (written by tools/profile.sh on the GPU box) into profiles/.
+"""Condense gpurun_out/prof_<tag>_<workload>/ (written by tools/profile.sh on the GPU box) into profiles/.
 
-    python tools/summarize_profile.py r01
+    python tools/summarize_profile.py r02 [workload]
 
-Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<tag>_pmc.json (per-kernel
-averages of every counter collected) and profiles/shade_hbm_traffic.json, which bench.py reads for
-roofline.traffic.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half
-their size, so reads are doubled before being compared with byte counts.
+Writes profiles/<tag>_<workload>_kernel_stats.csv (+ _isolated: rocprofv3 --kernel-trace --stats),
+profiles/<tag>_<workload>_pmc.json (per-kernel averages of every counter collected) and updates
+profiles/shade_roofline.json, which bench.py reads: per workload, the dominant kernel's executed FP32 flop per
+launch, HBM bytes per launch and VALU issue figures, with the hash of the kernel sources they were collected on.
+
+Executed FP32 flop = 64 lanes x (SQ_INSTS_VALU_ADD_F32 + SQ_INSTS_VALU_MUL_F32 + SQ_INSTS_VALU_TRANS_F32
++ 2 x SQ_INSTS_VALU_FMA_F32): wave-level instruction counts, every lane counted (an upper bound of the useful flop).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size, so reads
+are doubled before being compared with byte counts.
 """
 import collections
 import csv
@@ -17,21 +22,23 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+wl = sys.argv[2] if len(sys.argv) > 2 else "pool_n16_4k"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
-stats = glob.glob(os.path.join(src, "trace_isolated", "*", "*_kernel_stats.csv"))
-if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats_isolated.csv"))
+for sub, suffix in (("trace", ""), ("trace_isolated", "_isolated")):
+    stats = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_{wl}_kernel_stats{suffix}.csv"))
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for name in ("pmc_sq", "pmc_fetch", "pmc_write"):
+for name in ("pmc_sq", "pmc_class", "pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
@@ -48,24 +55,37 @@ for k, cs in pmc.items():
     out[k]["launches_per_pass"] = len(next(iter(cs.values())))
     if dur[k]:
         out[k]["ms_under_pmc"] = sum(dur[k]) / len(dur[k])
-json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1, sort_keys=True)
+json.dump(out, open(os.path.join(dst, f"{tag}_{wl}_pmc.json"), "w"), indent=1, sort_keys=True)
 
-kname = next((k for k in out if k.startswith("k_shade_fast")), None)
-if kname:
+# the dominant kernel: the shading kernel with the most VALU instructions
+shade = {k: c for k, c in out.items() if k.startswith(("k_shade_fast", "k_shade_general"))}
+if shade:
+    kname = max(shade, key=lambda k: shade[k].get("SQ_INSTS_VALU", 0.0))
     c = out[kname]
-    fetch, write = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
-    ms = c.get("ms_under_pmc", 0.0)
-    clk = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / (ms * 1e-3) / 1e9 if ms else None  # counter is summed over 8 XCDs
-    cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
-    valu = c.get("SQ_INSTS_VALU", 0.0)
-    summary = {
-        "kernel": kname, "profile": tag,
+    g = lambda n: c.get(n, 0.0)
+    fetch, write, ms = g("FETCH_SIZE"), g("WRITE_SIZE"), g("ms_under_pmc")
+    cyc = g("GRBM_GUI_ACTIVE") / 8.0          # the counter is summed over the 8 XCDs
+    valu = g("SQ_INSTS_VALU")
+    flop = 64.0 * (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_TRANS_F32") + 2.0 * g("SQ_INSTS_VALU_FMA_F32"))
+    entry = {
+        "kernel": kname, "profile": f"{tag}_{wl}", "kernel_source_hash": kernel_source_hash(),
+        "executed_fp32_flop_per_launch": flop,
         "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-        "fetch_size_kib": fetch, "write_size_kib": write,
+        "ms_under_pmc": ms,
+        "counters": {n: g(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
+                                       "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32",
+                                       "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_FMA_F64", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU",
+                                       "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE") if n in c},
+        "valu_issue": {"cycles_per_valu_inst_per_simd": (cyc * 1024.0 / valu) if valu else None,
+                       "effective_clock_ghz": (cyc / (ms * 1e-3) / 1e9) if ms else None,
+                       "fp32_share_of_valu_insts": (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_TRANS_F32") +
+                                                    g("SQ_INSTS_VALU_FMA_F32")) / valu if valu else None,
+                       "note": "in-kernel measurement of this chip (profiles/r02_valu_cycles.txt): v_fma_f32 3.7-4.0, v_pk_fma_f32 4.2, "
+                               "v_add/mul_f32 2.9, v_cvt / v_mul_lo_u32 / v_max_f32 4.2, v_xor / v_mov 2.3 cycles per wave instruction per SIMD"},
         "note": "FETCH_SIZE doubled (gfx950 counts wide reads at half size); WRITE_SIZE as reported",
-        "valu_insts_per_launch": valu, "salu_insts_per_launch": c.get("SQ_INSTS_SALU"),
-        "ms_under_pmc": ms, "effective_clock_ghz": clk,
-        "cycles_per_valu_inst_per_simd": (cyc * 1024.0 / valu) if valu else None,
     }
-    json.dump(summary, open(os.path.join(dst, "shade_hbm_traffic.json"), "w"), indent=1)
-    print(json.dumps(summary, indent=1))
+    path = os.path.join(dst, "shade_roofline.json")
+    allw = json.load(open(path)) if os.path.exists(path) else {}
+    allw[wl] = entry
+    json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(entry, indent=1))
