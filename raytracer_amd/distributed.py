@@ -193,7 +193,11 @@ class DistributedRenderer:
         self.device = dev
         self.lanes = []
         self.to_host = bool(to_host)
-        streams = concurrent_streams(torch, dev, pipelines) if pipelines > 1 else [None]
+        # the copy stream needs a hardware queue of its own as well: on a queue shared with a pipeline its copies would
+        # wait behind that pipeline's kernels, and those behind the copy
+        n_streams = pipelines + (1 if to_host else 0)
+        streams = concurrent_streams(torch, dev, n_streams) if n_streams > 1 else [None]
+        copy_stream = streams.pop() if to_host else None
         for i in range(pipelines):
             if i == 0:
                 r = renderer
@@ -209,7 +213,7 @@ class DistributedRenderer:
         self.next_lane = 0
         self.copy_stream = None
         if self.to_host and self.rank == 0:
-            self.copy_stream = torch.cuda.Stream(device=dev)
+            self.copy_stream = copy_stream
             for lane in self.lanes:
                 lane.host = [torch.empty((self.H, self.W, 3), dtype=torch.uint8).pin_memory() for _ in lane.gs]
                 lane.copied = [torch.cuda.Event() for _ in lane.gs]
