@@ -212,9 +212,10 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
                   uint32_t* count);
 
 /* Jitter stream contract, exported so tests can pin host == device == oracle.
- * Writes the two 16-bit integers of sample s of grid (seed,pixel,node,light).       */
-void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s,
-                    uint32_t* u16, uint32_t* v16);
+ * Writes the two 8-bit integers of sample s = i*n + j of the n x n grid (seed,pixel,node,light):
+ * the reference's two np.random.random() draws of that sample (light.py:53-54) are u/256, v/256. */
+void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t n, uint32_t s,
+                    uint32_t* u8, uint32_t* v8);
 
 #ifdef __cplusplus
 }

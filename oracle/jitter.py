@@ -18,9 +18,13 @@ both sides are driven by a stream keyed on *what* is being sampled instead of
     draw  = 2*(i*N+j) + axis   (axis 0 = u, 1 = v), i outer / j inner as in
             light.py:51-52
 
-One 32-bit hash per sample yields both coordinates: u from its high 16 bits, v
-from its low 16 bits.  Every value is a 16-bit integer scaled by 2**-16, so it is
-exact in float32 and float64 alike (and so is cell index + value for N < 256).
+One 32-bit hash serves TWO neighbouring samples of a row of the grid, one byte per
+coordinate: samples (i, 2q) and (i, 2q+1) share the hash of counter i*ceil(N/2) + q; the
+even sample takes bytes 3 (u) and 2 (v), the odd one bytes 1 (u) and 0 (v).  Every value is
+an 8-bit integer scaled by 2**-8 -- 1/256 of a grid cell, i.e. 1/4096 of the light's edge at
+N = 16 -- so it is exact in float32 and float64 alike, and so is cell index + value.  (On the
+GPU the hash is the larger part of the per-sample arithmetic; halving it and extracting
+bytes, which the hardware converts to float in one instruction, is what the layout is for.)
 """
 
 M32 = 0xFFFFFFFF
@@ -47,13 +51,20 @@ def stream_key(seed: int, pixel: int, node: int, light: int) -> int:
     return k
 
 
-def sample_bits(key: int, s: int):
-    """The two 16-bit integers (u, v) of sample ``s = i*N+j`` of a grid."""
-    m = mix32((key + s * GOLDEN) & M32)
-    return m >> 16, m & 0xFFFF
+JITTER_STEPS = 256
 
 
-def uniform(seed: int, pixel: int, node: int, light: int, draw: int) -> float:
-    """Value handed to the reference in place of ``np.random.random()``."""
-    u, v = sample_bits(stream_key(seed, pixel, node, light), draw >> 1)
-    return (v if (draw & 1) else u) * (1.0 / 65536.0)
+def sample_bits(key: int, n: int, s: int):
+    """The two 8-bit integers (u, v) of sample ``s = i*n+j`` of an ``n`` x ``n`` grid."""
+    i, j = divmod(s, n)
+    pair = i * ((n + 1) >> 1) + (j >> 1)
+    m = mix32((key + pair * GOLDEN) & M32)
+    if j & 1:
+        return (m >> 8) & 0xFF, m & 0xFF
+    return m >> 24, (m >> 16) & 0xFF
+
+
+def uniform(seed: int, pixel: int, node: int, light: int, n: int, draw: int) -> float:
+    """Value handed to the reference in place of ``np.random.random()`` (``n`` = grid edge, light.py:35)."""
+    u, v = sample_bits(stream_key(seed, pixel, node, light), n, draw >> 1)
+    return (v if (draw & 1) else u) * (1.0 / JITTER_STEPS)

@@ -272,10 +272,10 @@ def item_kat(pool, only):
     cross = np.array([np.cross(a, b) for a, b in zip(A, B)])
     np.savez_compressed(os.path.join(GOLD, "kat", "numerics.npz"), a=A, b=B, dot=dots, norm=norms, unit=unit, sum=sums, cross=cross)
     table = []
-    for seed, pixel, node, light, s in [(0, 0, 1, 0, 0), (0, 1, 1, 0, 0), (0, 123456, 1, 4, 24), (7, 8294399, 2, 1, 255),
-                                        (0xFFFFFFFF, 42, 1023, 0, 3), (1, 2, 3, 4, 5), (0, 250000, 5, 2, 17), (99, 77, 6, 0, 1)]:
-        u, v = jitter.sample_bits(jitter.stream_key(seed, pixel, node, light), s)
-        table.append({"seed": seed, "pixel": pixel, "node": node, "light": light, "s": s, "u": u, "v": v})
+    for seed, pixel, node, light, n, s in [(0, 0, 1, 0, 5, 0), (0, 1, 1, 0, 5, 1), (0, 123456, 1, 4, 5, 24), (7, 8294399, 2, 1, 16, 255),
+                                           (0xFFFFFFFF, 42, 1023, 0, 2, 3), (1, 2, 3, 4, 3, 5), (0, 250000, 5, 2, 5, 17), (99, 77, 6, 0, 1, 0)]:
+        u, v = jitter.sample_bits(jitter.stream_key(seed, pixel, node, light), n, s)
+        table.append({"seed": seed, "pixel": pixel, "node": node, "light": light, "n": n, "s": s, "u": u, "v": v})
     with open(os.path.join(GOLD, "kat", "jitter_kat.json"), "w") as f:
         json.dump(table, f, indent=1)
     print("kat done", len(kinds), flush=True)

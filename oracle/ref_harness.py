@@ -73,6 +73,7 @@ class Probe:
         self.pixel = 0
         self.node = 1
         self.light = 0
+        self.grid = 1
         self.draw = 0
         self.reset_counters()
 
@@ -130,13 +131,14 @@ def instrumented(scene, seed=0, counter_jitter=True, record_hits=False):
 
     def gen(self, right, up, n):
         probe.light = light_index[id(self)]
+        probe.grid = int(n)
         probe.draw = 0
         return saved["gen"](self, right, up, n)
 
     def rand(*a, **k):
         if a or k:
             return saved["rand"](*a, **k)
-        v = jitter.uniform(probe.seed, probe.pixel, probe.node, probe.light, probe.draw)
+        v = jitter.uniform(probe.seed, probe.pixel, probe.node, probe.light, probe.grid, probe.draw)
         probe.draw += 1
         return v
 

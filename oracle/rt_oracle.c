@@ -107,14 +107,16 @@ static inline uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t node, 
     k = mix32(k ^ ((light + 1u) * 0x85EBCA6Bu));
     return k;
 }
-static inline void sample_bits(uint32_t key, uint32_t s, uint32_t* u, uint32_t* v) {
-    uint32_t m = mix32(key + s * 0x9E3779B9u);
-    *u = m >> 16;
-    *v = m & 0xFFFFu;
+/* sample s = i*n + j of an n x n grid: one hash per two neighbours of a row, one byte per coordinate */
+static inline void sample_bits(uint32_t key, uint32_t n, uint32_t s, uint32_t* u, uint32_t* v) {
+    uint32_t i = s / n, j = s % n;
+    uint32_t m = mix32(key + (i * ((n + 1u) >> 1) + (j >> 1)) * 0x9E3779B9u);
+    if (j & 1u) { *u = (m >> 8) & 0xFFu; *v = m & 0xFFu; }
+    else { *u = m >> 24; *v = (m >> 16) & 0xFFu; }
 }
-void rto_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s,
-                     uint32_t* u16, uint32_t* v16) {
-    sample_bits(stream_key(seed, pixel, node, light), s, u16, v16);
+void rto_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t n, uint32_t s,
+                     uint32_t* u8, uint32_t* v8) {
+    sample_bits(stream_key(seed, pixel, node, light), n, s, u8, v8);
 }
 
 /* ---- scalar intersections ----------------------------------------------------- */
@@ -277,9 +279,9 @@ static double shadow_ratio(const scene_t* sc, ctx_t* cx, v3 hit, int li, uint32_
     for (int i = 0; i < N; ++i)
         for (int j = 0; j < N; ++j) {
             int s = i * N + j;
-            uint32_t ub, vb; sample_bits(key, (uint32_t)s, &ub, &vb);
-            double u = (i + ub * (1.0 / 65536.0)) / N;
-            double v = (j + vb * (1.0 / 65536.0)) / N;
+            uint32_t ub, vb; sample_bits(key, (uint32_t)N, (uint32_t)s, &ub, &vb);
+            double u = (i + ub * (1.0 / 256.0)) / N;
+            double v = (j + vb * (1.0 / 256.0)) / N;
             u = u - 0.5; v = v - 0.5;
             v3 off = add(scl(right, u * lt->radius), scl(up, v * lt->radius));
             v3 smp = add(lt->pos, off);

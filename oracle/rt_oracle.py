@@ -46,7 +46,7 @@ def lib():
         L.rto_intersect_batch.restype = C.c_double
         L.rto_intersect_batch.argtypes = [C.c_int] + [C.c_void_p] * 3
         L.rto_jitter_bits.restype = None
-        L.rto_jitter_bits.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)] * 2
+        L.rto_jitter_bits.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)] * 2
         _lib = L
     return _lib
 
@@ -117,7 +117,7 @@ def intersect_batch(kind, params, o, d):
     return lib().rto_intersect_batch(int(kind), p.ctypes.data, o.ctypes.data, d.ctypes.data)
 
 
-def jitter_bits(seed, pixel, node, light, s):
+def jitter_bits(seed, pixel, node, light, n, s):
     u, v = C.c_uint32(0), C.c_uint32(0)
-    lib().rto_jitter_bits(seed, pixel, node, light, s, C.byref(u), C.byref(v))
+    lib().rto_jitter_bits(seed, pixel, node, light, n, s, C.byref(u), C.byref(v))
     return u.value, v.value

@@ -1045,11 +1045,11 @@ int rt_debug_hits(rt_handle* h, const rt_render_params* p, uint32_t capacity, ui
     return RT_OK;
 }
 
-void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t s, uint32_t* u16, uint32_t* v16) {
-    uint32_t u, v;
-    rt_sample_bits(rt_grid_key(rt_seed_key(seed), pixel, node, light), s, u, v);
-    if (u16) *u16 = u;
-    if (v16) *v16 = v;
+void rt_jitter_bits(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light, uint32_t n, uint32_t s, uint32_t* u8, uint32_t* v8) {
+    uint32_t u = 0, v = 0;
+    if (n) rt_sample_bits(rt_grid_key(rt_seed_key(seed), pixel, node, light), n, s / n, s % n, u, v);
+    if (u8) *u8 = u;
+    if (v8) *v8 = v;
 }
 
 }  // extern "C"

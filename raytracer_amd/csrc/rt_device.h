@@ -152,10 +152,17 @@ __host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixe
     k = rt_mix32(k ^ ((light + 1u) * 0x85EBCA6Bu));
     return k;
 }
-__host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t s, uint32_t& u, uint32_t& v) {
-    uint32_t m = rt_mix32(key + s * 0x9E3779B9u);
-    u = m >> 16;
-    v = m & 0xFFFFu;
+// Sample (i, j) of an n x n grid: one hash per two neighbours of a row -- samples (i, 2q) and (i, 2q+1) share the
+// hash of counter i*ceil(n/2) + q -- and one byte per coordinate: the even sample takes bytes 3 (u) and 2 (v), the odd
+// one bytes 1 (u) and 0 (v).  The jitter is byte / 256 of a grid cell.
+#define RT_JITTER_INV 0.00390625f   // 2^-8
+__host__ __device__ inline uint32_t rt_pair_counter(uint32_t key, uint32_t n, uint32_t i, uint32_t q) {
+    return key + (i * ((n + 1u) >> 1) + q) * 0x9E3779B9u;
+}
+__host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t n, uint32_t i, uint32_t j, uint32_t& u, uint32_t& v) {
+    const uint32_t m = rt_mix32(rt_pair_counter(key, n, i, j >> 1));
+    if (j & 1u) { u = (m >> 8) & 0xFFu; v = m & 0xFFu; }
+    else { u = m >> 24; v = (m >> 16) & 0xFFu; }
 }
 
 // ---- launch wrappers implemented by the .hip files -------------------------------

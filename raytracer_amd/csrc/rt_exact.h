@@ -55,7 +55,7 @@ __device__ __forceinline__ OwnSphere own_sphere_setup(const double* p64, const d
 // divided out, and not even that when the comparison with 1e-6 / dist is decided by a margin no rounding bridges.
 __device__ __forceinline__ bool own_sphere_blocks_sample(const OwnSphere& o, const double* light, const SurfD& sph, int N, double inv_n,
                                                          int i, int j, uint32_t ub, uint32_t vb) {
-    const double un = (double)i + (double)ub * (1.0 / 65536.0), vn = (double)j + (double)vb * (1.0 / 65536.0);
+    const double un = (double)i + (double)ub * (1.0 / 256.0), vn = (double)j + (double)vb * (1.0 / 256.0);
     double u = inv_n != 0.0 ? un * inv_n : un / (double)N;               // light.py:53-57
     double v = inv_n != 0.0 ? vn * inv_n : vn / (double)N;
     u = u - 0.5; v = v - 0.5;
@@ -109,7 +109,7 @@ __device__ __forceinline__ bool own_sphere_blocks_centre(const double* p64, cons
 // direction and length of the shadow ray of sample (i, j), as the reference forms them (light.py:51-63, ray_tracer.py:56-59)
 __device__ __forceinline__ void sample_ray(const OwnSphere& o, const double* light, int N, double inv_n, int i, int j,
                                            uint32_t ub, uint32_t vb, e3& d, double& dist) {
-    const double un = (double)i + (double)ub * (1.0 / 65536.0), vn = (double)j + (double)vb * (1.0 / 65536.0);
+    const double un = (double)i + (double)ub * (1.0 / 256.0), vn = (double)j + (double)vb * (1.0 / 256.0);
     double u = inv_n != 0.0 ? un * inv_n : un / (double)N;
     double v = inv_n != 0.0 ? vn * inv_n : vn / (double)N;
     u = u - 0.5; v = v - 0.5;

@@ -165,6 +165,36 @@ __device__ __forceinline__ bool box_blocks_a(const SurfF& s, f3 P, f3 w, float d
 
 __device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
+// two FP32 values in an aligned register pair: arithmetic on them is one packed instruction (v_pk_fma_f32 ...)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 F2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// Packed FMA forms that read one half of an operand pair for BOTH results (op_sel / op_sel_hi), so that a per-lane
+// scalar is used as it lies in its register pair: the compiler has no such form and would keep a (x, x) copy of
+// every scalar, which costs the registers the kernel's occupancy depends on.
+//   op_sel[k]    : which half of source k feeds the LOW result  (0 = low half, 1 = high half)
+//   op_sel_hi[k] : which half of source k feeds the HIGH result
+__device__ __forceinline__ f2 pk_fma_bLcL(f2 a, f2 b, f2 c) {   // a * b.x + c.x
+    f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_fma_bLcH(f2 a, f2 b, f2 c) {   // a * b.x + c.y
+    f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_fma_bL(f2 a, f2 b, f2 c) {     // a * b.x + c
+    f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_fma_bH(f2 a, f2 b, f2 c) {     // a * b.y + c
+    f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_fma_cH(f2 a, f2 b, f2 c) {     // a * b + c.y
+    f2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d;
+}
+__device__ __forceinline__ f2 pk_add_bH(f2 a, f2 b) {           // a + b.y
+    f2 d; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// byte B of a word as a float: one instruction (v_cvt_f32_ubyteB)
+template <int B> __device__ __forceinline__ float ubyte_f32(uint32_t m) { return (float)((m >> (8 * B)) & 0xFFu); }
+
 struct HitRec {
     f3 P, nrm, view, wgt;
     uint32_t lpix, gpix, node, flags;
@@ -452,9 +482,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 for (int i = 0; i < N && reach_mask; ++i) {
                     for (int j = 0; j < N; ++j, ++s_idx) {
                         uint32_t ub, vb;
-                        rt_sample_bits(key, s_idx, ub, vb);
-                        const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
-                        const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
+                        rt_sample_bits(key, (uint32_t)N, (uint32_t)i, (uint32_t)j, ub, vb);
+                        const float u = ((float)i + (float)ub * RT_JITTER_INV) * invN - 0.5f;
+                        const float v = ((float)j + (float)vb * RT_JITTER_INV) * invN - 0.5f;
                         const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
                         const float d2 = dot(sv, sv);
                         const float dinv = __frsqrt_rn(d2);
@@ -587,9 +617,20 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     // the others).  With transparent surfaces only "nothing can block" decides a tile: a blocked
     // sample's factor depends on which entries block it.
     constexpr int T1 = 8, T2 = 8;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
-    const float cell = 65536.0f * ku;  // width of one grid cell in ur / vr units
+    const float cell = 256.0f * ku;    // width of one grid cell in ur / vr units
     uint32_t open_samples = 0;         // opaque scenes: samples nothing blocks
     float sum = 0.f;                   // otherwise: sum of the samples' light factors
+    // the rows as register pairs for the packed sample loop: (B, C) per row, the A of two rows share a pair
+    f2 BC[K > 0 ? K : 1], AA[K > 0 ? (K + 1) / 2 : 1];
+#pragma unroll
+    for (int e = 0; e < K; ++e) BC[e] = F2(Bd[e], Cd[e]);
+#pragma unroll
+    for (int e = 0; e < (K + 1) / 2; ++e) AA[e] = F2(Ad[2 * e], 2 * e + 1 < K ? Ad[2 * e + 1] : -INFINITY);
+    // row e for a pair of samples: A + ur * B + vr * C
+    auto row_pair = [&](int e, f2 ur, f2 vr) -> f2 {
+        const f2 t = (e & 1) ? pk_fma_bLcH(ur, BC[e], AA[e >> 1]) : pk_fma_bLcL(ur, BC[e], AA[e >> 1]);
+        return pk_fma_bH(vr, BC[e], t);
+    };
     // decided(i0,i1,j0,j1): false = undecided for some lane, true = decided for the whole wave (and accounted for)
     auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
         if (NB > 0) return false;  // boxes have no tile bound here: every sample is tested
@@ -618,6 +659,9 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         }
         return true;
     };
+#ifdef RT_EXP_NO_TILES   // timing experiment: classification only
+    return (float)(N * N);
+#endif
     for (int I0 = 0; I0 < N; I0 += T1) {
         const int I1 = I0 + T1 < N ? I0 + T1 : N;
         for (int J0 = 0; J0 < N; J0 += T1) {
@@ -629,48 +673,76 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                     const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
                     if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
                     n_generated += (uint32_t)((i1 - i0) * (j1 - j0));   // (wave-uniform)
+#ifdef RT_EXP_NO_SAMPLES   // timing experiment: everything but the sample loop
+                    continue;
+#endif
+                    // Two neighbouring samples of a row share one hash (rt_device.h) and are evaluated together in
+                    // packed FP32 (v_pk_fma_f32: both samples' FMA in one instruction): .x = sample j, .y = sample j + 1.
+                    // A tile starts at an even column, so pairs never straddle tiles; only the last pair of a row of
+                    // an odd grid has no second sample.
+                    const f2 KU = F2(ku, 2.f * cell);    // (jitter step, two columns)
+                    const f2 vcol0 = F2(fmaf((float)j0, cell, koff), fmaf((float)(j0 + 1), cell, koff));   // left edges of columns j0, j0 + 1
+                    const bool odd_tail = ((j1 - j0) & 1) != 0;
                     for (int i = i0; i < i1; ++i) {
-                        uint32_t ctr = key + (uint32_t)(i * N + j0) * 0x9E3779B9u;
+                        uint32_t ctr = rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j0 >> 1);
                         uint32_t mask = 0;
-                        const float urow = fmaf((float)i, cell, koff);  // left edge of row i
-                        for (int j = j0; j < j1; ++j) {
+                        const f2 UL = F2(fmaf((float)i, cell, koff), lc2);  // (left edge of row i, |lrel|^2)
+                        f2 vcol = vcol0;
+                        float row_sum = 0.f;
+                        for (int j = j0; j < j1; j += 2) {
                             const uint32_t mm = rt_mix32(ctr);
                             ctr += 0x9E3779B9u;
-                            const float ur = fmaf((float)(mm >> 16), ku, urow);
-                            // (cell index << 16) | 16-bit jitter: the cell index rides above the jitter bits
-                            const float vr = fmaf((float)((mm & 0xFFFFu) | ((uint32_t)j << 16)), ku, koff);
-                            const float len2 = fmaf(ur, ur, fmaf(vr, vr, lc2));
+                            const f2 ub = F2(ubyte_f32<3>(mm), ubyte_f32<1>(mm));
+                            const f2 vb = F2(ubyte_f32<2>(mm), ubyte_f32<0>(mm));
+                            const f2 ur = pk_fma_bLcL(ub, KU, UL);
+                            const f2 vr = pk_fma_bL(vb, KU, vcol);
+                            vcol = pk_add_bH(vcol, KU);
+                            const f2 len2 = pk_fma(ur, ur, pk_fma_cH(vr, vr, UL));
                             if (ALL_OPAQUE) {
-                                float vmax = K > 0 ? fmaf(vr, Cd[0], fmaf(ur, Bd[0], Ad[0])) : -INFINITY;
+                                f2 vmax = F2(-INFINITY, -INFINITY);
+                                if (K > 0) vmax = row_pair(0, ur, vr);
 #pragma unroll
-                                for (int e = 1; e < K; ++e)
-                                    vmax = __builtin_fmaxf(vmax, fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e])));
-                                float res = fmaf(vmax, fabsf(vmax), -len2);
+                                for (int e = 1; e < K; ++e) {
+                                    const f2 lin = row_pair(e, ur, vr);
+                                    vmax.x = __builtin_fmaxf(vmax.x, lin.x); vmax.y = __builtin_fmaxf(vmax.y, lin.y);
+                                }
+                                float res0 = fmaf(vmax.x, fabsf(vmax.x), -len2.x), res1 = fmaf(vmax.y, fabsf(vmax.y), -len2.y);
                                 if (NB > 0) {
                                     float val[NB > 0 ? NB : 1];
-                                    box_values<NB>(bx, ur, vr, val);
+                                    box_values<NB>(bx, ur.x, vr.x, val);
 #pragma unroll
-                                    for (int b = 0; b < NB; ++b) res = __builtin_fmaxf(res, val[b]);
+                                    for (int b = 0; b < NB; ++b) res0 = __builtin_fmaxf(res0, val[b]);
+                                    box_values<NB>(bx, ur.y, vr.y, val);
+#pragma unroll
+                                    for (int b = 0; b < NB; ++b) res1 = __builtin_fmaxf(res1, val[b]);
                                 }
                                 // sign bit set <=> nothing blocks this sample
-                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res), 31);
+                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res0), 31);
+                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res1), 31);
                             } else {
-                                float f = 1.f;
+                                float f0 = 1.f, f1 = 1.f;
 #pragma unroll
                                 for (int e = 0; e < K; ++e) {
-                                    const float lin = fmaf(vr, Cd[e], fmaf(ur, Bd[e], Ad[e]));
-                                    f = fmaf(lin, fabsf(lin), -len2) >= 0.f ? f * tr[e] : f;
+                                    const f2 lin = row_pair(e, ur, vr);
+                                    f0 = fmaf(lin.x, fabsf(lin.x), -len2.x) >= 0.f ? f0 * tr[e] : f0;
+                                    f1 = fmaf(lin.y, fabsf(lin.y), -len2.y) >= 0.f ? f1 * tr[e] : f1;
                                 }
                                 if (NB > 0) {
                                     float val[NB > 0 ? NB : 1];
-                                    box_values<NB>(bx, ur, vr, val);
+                                    box_values<NB>(bx, ur.x, vr.x, val);
 #pragma unroll
-                                    for (int b = 0; b < NB; ++b) f = val[b] >= 0.f ? f * bx.tr[b] : f;
+                                    for (int b = 0; b < NB; ++b) f0 = val[b] >= 0.f ? f0 * bx.tr[b] : f0;
+                                    box_values<NB>(bx, ur.y, vr.y, val);
+#pragma unroll
+                                    for (int b = 0; b < NB; ++b) f1 = val[b] >= 0.f ? f1 * bx.tr[b] : f1;
                                 }
-                                sum += f;
+                                row_sum += f0 + ((j + 1 < j1) ? f1 : 0.f);
                             }
                         }
-                        if (ALL_OPAQUE) open_samples += (uint32_t)__popc(mask);
+                        if (ALL_OPAQUE) {
+                            if (odd_tail) mask &= ~1u;   // the bit shifted in last belongs to no sample
+                            open_samples += (uint32_t)__popc(mask);
+                        } else sum += row_sum;
                     }
                 }
             }
@@ -916,7 +988,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                             if (!ALL_OPAQUE && sl == SM) trd[e] = own_sf.b.w;
                         }
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-                        const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
+                        const float ku = RT_JITTER_INV * invN * lt.radius;  // 2^-8 / N * radius
                         const float koff = -0.5f * lt.radius;
                         BoxSet bx;
                         if (HAS_BOX && nb > 0) {
@@ -1120,7 +1192,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const f3 right = normalize(cross(ldir, perp));
             const f3 up = normalize(cross(right, ldir));
             const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-            const float ku = 1.52587890625e-05f * invN * lt.radius;  // 2^-16 / N * radius
+            const float ku = RT_JITTER_INV * invN * lt.radius;  // 2^-8 / N * radius
             if (wv == 0) {
                 // own sphere with c > 0 and a sample that may enter it steeply: the loop below applies the rule ("never
                 // blocks") and k_shade_exact adds the float64 correction (same predicate as in k_shade_fast)
@@ -1148,11 +1220,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             float sum = 0.f;
             for (int i = wv; i < N; i += NWV) {
                 const float cu = ((float)i * invN - 0.5f) * lt.radius;
-                uint32_t ctr = key + (uint32_t)(i * N) * 0x9E3779B9u;
+                uint32_t mm = 0;
                 for (int j = 0; j < N; ++j) {
-                    uint32_t ub, vb;
-                    rt_sample_bits(ctr, 0u, ub, vb);
-                    ctr += 0x9E3779B9u;
+                    if (!(j & 1)) mm = rt_mix32(rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j >> 1));   // one hash per two samples
+                    const uint32_t ub = (j & 1) ? (mm >> 8) & 0xFFu : mm >> 24;
+                    const uint32_t vb = (j & 1) ? mm & 0xFFu : (mm >> 16) & 0xFFu;
                     const float cv = ((float)j * invN - 0.5f) * lt.radius;
                     const float ur = fmaf((float)ub, ku, cu);
                     const float vr = fmaf((float)vb, ku, cv);
@@ -1297,9 +1369,9 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
         for (uint32_t s_idx = 0; s_idx < (uint32_t)(N * N); ++s_idx) {
             const int i = (int)(s_idx / (uint32_t)N), j = (int)(s_idx % (uint32_t)N);
             uint32_t ub, vb;
-            rt_sample_bits(key, s_idx, ub, vb);
-            const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
-            const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
+            rt_sample_bits(key, (uint32_t)N, (uint32_t)i, (uint32_t)j, ub, vb);
+            const float u = ((float)i + (float)ub * RT_JITTER_INV) * invN - 0.5f;
+            const float v = ((float)j + (float)vb * RT_JITTER_INV) * invN - 0.5f;
             const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
             const float d2 = dot(sv, sv);
             const float dinv = __frsqrt_rn(d2);
@@ -1393,9 +1465,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
             const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
             auto sample = [&](uint32_t s_idx, int& i, int& j, uint32_t& ub, uint32_t& vb, f3& w, float& dist) {
                 i = (int)(s_idx / (uint32_t)N); j = (int)(s_idx % (uint32_t)N);
-                rt_sample_bits(key, s_idx, ub, vb);
-                const float u = ((float)i + (float)ub * 1.52587890625e-05f) * invN - 0.5f;
-                const float v = ((float)j + (float)vb * 1.52587890625e-05f) * invN - 0.5f;
+                rt_sample_bits(key, (uint32_t)N, (uint32_t)i, (uint32_t)j, ub, vb);
+                const float u = ((float)i + (float)ub * RT_JITTER_INV) * invN - 0.5f;
+                const float v = ((float)j + (float)vb * RT_JITTER_INV) * invN - 0.5f;
                 const f3 sv = lrel + right * (u * lt.radius) + up * (v * lt.radius);
                 const float d2 = dot(sv, sv);
                 const float dinv = __frsqrt_rn(d2);

@@ -64,14 +64,14 @@ def load_library():
     L.rt_debug_hits.restype = C.c_int
     L.rt_debug_hits.argtypes = [vp, C.POINTER(packing.RtRenderParams), C.c_uint32] + [vp] * 7 + [C.POINTER(C.c_uint32)]
     L.rt_jitter_bits.restype = None
-    L.rt_jitter_bits.argtypes = [C.c_uint32] * 5 + [C.POINTER(C.c_uint32)] * 2
+    L.rt_jitter_bits.argtypes = [C.c_uint32] * 6 + [C.POINTER(C.c_uint32)] * 2
     _lib = L
     return L
 
 
-def jitter_bits(seed, pixel, node, light, s):
+def jitter_bits(seed, pixel, node, light, n, s):
     u, v = C.c_uint32(0), C.c_uint32(0)
-    load_library().rt_jitter_bits(seed & 0xFFFFFFFF, pixel, node, light, s, C.byref(u), C.byref(v))
+    load_library().rt_jitter_bits(seed & 0xFFFFFFFF, pixel, node, light, n, s, C.byref(u), C.byref(v))
     return u.value, v.value
 
 

@@ -49,6 +49,14 @@ __global__ __launch_bounds__(256) void probe(Stamp* out, float seed, int iters) 
             if (OP == 13) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(u[i]) : "v"(um), "v"(um));
             if (OP == 14) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(p[i]) : "v"(pm));
             if (OP == 15) asm volatile("v_mov_b32 %0, %1" : "=v"(u[i]) : "v"(um));
+            if (OP == 16) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            if (OP == 17) asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(a[i]) : "v"(u[i]));
+            if (OP == 18) asm volatile("v_xor_b32_sdwa %0, %0, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(u[i]));
+            if (OP == 19) asm volatile("v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "+v"(p[i]) : "v"(pm), "v"(pc));
+            if (OP == 20) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,1]" : "+v"(p[i]) : "v"(pc));
+            if (OP == 21) asm volatile("v_fma_f32 %0, %0, |%0|, -%1" : "+v"(a[i]) : "v"(c));
+            if (OP == 22) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (OP == 23) asm volatile("v_bcnt_u32_b32 %0, %0, 0" : "+v"(u[i]));
         }
     }
     asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) :: "memory");
@@ -65,7 +73,8 @@ __global__ __launch_bounds__(256) void probe(Stamp* out, float seed, int iters) 
 
 static const char* names[] = {"v_fma_f32", "v_pk_fma_f32", "v_mul_lo_u32", "v_xor_b32", "v_cvt_f32_u32", "v_max_f32",
                               "v_add_f32", "v_mul_f32", "v_lshrrev_b32", "v_alignbit_b32", "v_and_or_b32", "v_rsq_f32",
-                              "v_fmac_f32", "v_mad_u32_u24", "v_pk_mul_f32", "v_mov_b32"};
+                              "v_fmac_f32", "v_mad_u32_u24", "v_pk_mul_f32", "v_mov_b32", "v_cvt_f32_ubyte1", "v_cvt_f32_ubyte3",
+                              "v_xor_b32_sdwa", "v_pk_fma_f32 op_sel", "v_pk_add_f32 op_sel", "v_fma_f32 |x| -y", "v_max3_f32", "v_bcnt_u32_b32"};
 
 template <int OP>
 static void run(int cus, int w) {
@@ -109,5 +118,6 @@ int main() {
     const int cus = p.multiProcessorCount;
     sweep<0>(cus); sweep<1>(cus); sweep<2>(cus); sweep<3>(cus); sweep<4>(cus); sweep<5>(cus); sweep<6>(cus); sweep<7>(cus);
     sweep<8>(cus); sweep<9>(cus); sweep<10>(cus); sweep<11>(cus); sweep<12>(cus); sweep<13>(cus); sweep<14>(cus); sweep<15>(cus);
+    sweep<16>(cus); sweep<17>(cus); sweep<18>(cus); sweep<19>(cus); sweep<20>(cus); sweep<21>(cus); sweep<22>(cus); sweep<23>(cus);
     return 0;
 }
