@@ -751,6 +751,49 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     return ALL_OPAQUE ? (float)open_samples : sum;
 }
 
+// Wave-level pre-test of one (light, surface) combination, evaluated by ONE lane for the whole 64-hit chunk: can the
+// surface matter for ANY hit of the chunk?  The hits lie within Rw of Pc, so every segment hit -> sample lies within Rw
+// of the corresponding segment from Pc, and the per-hit reach tests of the classification (same forms, same margins)
+// hold for all of them once Rw and the bounds of the hit-dependent allowances are added.  false: the classification of
+// that combination would find "never" in every lane, and is skipped.  Errs only towards true.
+__device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, int l, int s, f3 Pc, float Rw, bool own_uniform, int own_grp) {
+    const LightF* lt = a.light + l;
+    const SurfF* sf = a.surf + s;
+    const f3 Lp = F3(lt->pos[0], lt->pos[1], lt->pos[2]);
+    const f3 lrel = Lp - Pc;
+    const float lc2 = dot(lrel, lrel);
+    const float llen = __builtin_amdgcn_sqrtf(lc2);
+    const float pabs = fabsf(Pc.x) + fabsf(Pc.y) + fabsf(Pc.z);
+    const float rho = lt->radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (llen + pabs + 4.f * Rw);   // >= every lane's rho
+    const int type = sf->type;
+    const bool own_all = own_uniform && sf->pad == own_grp;   // every hit of the chunk lies on this surface (or a twin)
+    if (type == RT_SURF_PLANE) {
+        if (own_all) return false;
+        const f3 n = F3(sf->a.x, sf->a.y, sf->a.z);
+        const float hh = sf->a.w - dot(Pc, n);          // the hits' side of the plane ...
+        const float hl = sf->a.w - dot(Lp, n);          // ... and the light's: |ah - dn0| of the classification is sg * hl
+        const float ah = fabsf(hh), dn = fabsf(dot(lrel, n));
+        const float fuzz = 2e-6f * (fabsf(sf->a.w) + pabs + fabsf(Lp.x) + fabsf(Lp.y) + fabsf(Lp.z) + Rw);
+        const bool one_side = ah > Rw * 1.001f + fuzz;
+        const float sg = hh < 0.f ? -1.f : 1.f;
+        const bool never = one_side && sg * hl > rho * 1.0003f + 1e-5f * (ah + dn + 2.f * Rw) + fuzz;
+        return !never;
+    }
+    const bool sph = type == RT_SURF_SPHERE;
+    if (sph && own_all) return false;                    // the own sphere has its own entry in the classification
+    if (!sph && own_all) return true;                    // the own box: a sample may enter it
+    const f3 oc = Pc - (sph ? F3(sf->a.x, sf->a.y, sf->a.z) : F3(sf->c.x, sf->c.y, sf->c.z));
+    const float rad = sph ? sf->c.x : sf->c.w;
+    const float t = lc2 > 0.f ? fminf(fmaxf(-dot(oc, lrel) / lc2, 0.f), 1.f) : 0.f;
+    const f3 q = oc + lrel * t;
+    // the segments fan out from the hits: at parameter s they are within Rw + s * rho of the axis Pc -> L, and a contact
+    // needs |s - t| * llen <= rad + Rw + s * rho, which bounds s (the classification's s_hi, with Rw added to the radius)
+    const float radw = rad + Rw * 1.001f;
+    const float s_hi = llen > 1.5f * rho + Rw ? 1.0003f * (radw + t * llen) / (llen - rho - Rw) : 1e30f;
+    const float lim = radw + rho * fminf(1.f, s_hi) * 1.0003f + 2e-6f * (fabsf(oc.x) + fabsf(oc.y) + fabsf(oc.z) + llen);
+    return !(dot(q, q) > lim * lim * 1.0003f);           // (NaN: true)
+}
+
 template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k_shade_fast(ShadeArgs a) {
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
@@ -781,7 +824,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
     for (;;) {
         if (grab >= grab_end) {
             // batches of 4 while plenty of work is left, single items towards the end
+#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the shared work counter out of the picture
+            const uint32_t batch = RT_EXP_BATCH;
+#else
             const uint32_t batch = (grab_end + 16u * n_waves < n_items) ? 4u : 1u;
+#endif
             uint32_t g0 = 0;
             if (lane == 0) g0 = atomicAdd(a.work, batch);
             grab = __builtin_amdgcn_readfirstlane(g0);
@@ -806,8 +853,38 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
         const float pfuzz_hit = 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z));
         const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
 
+        // ---- which (light, surface) combinations can matter for this chunk at all?  One lane per combination
+        //      (chunk_may_reach), all lights at once; bit l * S + s of premask.  Most chunks are an 8 x 8 pixel tile on
+        //      one surface, a few hundredths of a scene unit across, and reach one surface per light or none.
+        unsigned long long premask = ~0ull;
+        const bool prefilter = classify && L * S <= 64;
+        if (prefilter) {
+            const f3 Pc = F3(__builtin_amdgcn_readfirstlane(P.x), __builtin_amdgcn_readfirstlane(P.y), __builtin_amdgcn_readfirstlane(P.z));
+            const f3 dP = P - Pc;
+            float rw2 = dot(dP, dP);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rw2 = fmaxf(rw2, __shfl_xor(rw2, o));
+            const float Rw = __builtin_amdgcn_sqrtf(rw2) * 1.0001f;
+            const int grp0 = __builtin_amdgcn_readfirstlane(own_sf.pad);
+            const bool own_uniform = !__any(!own_valid || own_sf.pad != grp0);
+            const int cl = (int)lane / S, cs = (int)lane - cl * S;
+            const bool maybe = (int)lane < L * S && chunk_may_reach(a, cl, cs, Pc, Rw, own_uniform, grp0);
+            premask = __ballot(maybe);
+        }
+#ifdef RT_EXP_COUNT_PREMASK // experiment: combinations that survive the pre-test, reported in the single-ray class
+        wl_n[6] += (uint32_t)__popcll(premask);
+#endif
+#ifdef RT_EXP_NO_CLASSIFY   // timing experiment: no surface is classified
+        premask = 0ull;
+#endif
+
         double cx = 0.0, cy = 0.0, cz = 0.0;   // lights summed in float64 (see k_shade_general)
+#ifdef RT_EXP_NO_LIGHTS     // timing experiment: load and accumulate only
+        cx = P.x; cy = P.y; cz = P.z;
+        for (int l = 0; l < 0; ++l) {
+#else
         for (int l = 0; l < L; ++l) {
+#endif
             if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
@@ -838,13 +915,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                 const float ndl0 = dot(h.nrm, ldir);
                 const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
+                const bool any_lit = __any(lit && active);   // a light behind every hit of the chunk: nothing to classify
                 float A[(SM + 1)], B[(SM + 1)], C[(SM + 1)];
                 bool gen = false;
                 uint32_t lin = 0, reach_bits = 0, box_bits = 0;
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
                     A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
-                    if (j < S) {
+                    if (j < S && any_lit && (!prefilter || ((premask >> (l * S + j)) & 1ull))) {   // (wave-uniform)
                         const SurfF sf = a.surf[j];
                         const bool own = own_valid && sf.pad == own_sf.pad;   // the own surface or a twin of it
                         if (STYPE(j) == RT_SURF_SPHERE) {
