@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                             const int sl = rem ? (int)__builtin_ctz(rem) : -1;
                             rem &= rem - 1u;
                             Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
+                            if (e >= k) continue;   // (wave-uniform) only the first k entries are filled: the others stay inert
 #pragma unroll
                             for (int t = 0; t < (SM + 1); ++t) {
                                 if (sl == t) {
