@@ -82,7 +82,6 @@ struct rt_handle {
     hipStream_t stream = nullptr;
     std::string err;
     int n_cu = 256;
-    int shade_blocks_per_cu = 4;
 
     // scene
     bool has_scene = false;
@@ -395,7 +394,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.special = h->d_special;
         sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
         sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
-        rt_launch_shade(sa, h->n_cu * h->shade_blocks_per_cu, st, ev[4]);
+        rt_launch_shade(sa, h->n_cu, st, ev[4]);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->fm.d_accum, (int64_t)pixels, d_f32, d_u8, st);

@@ -221,6 +221,6 @@ struct ShadeArgs {
     unsigned long long* counters;
 };
 // after_main (may be null) is recorded behind the first, dominant launch
-void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s, hipEvent_t after_main);
+void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main);
 
 void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s);

@@ -587,6 +587,11 @@ struct BoxSet {
     f3 lrel, right, up;
     float lo[NBMAX][3], hi[NBMAX][3];  // corners relative to the hit point
     float tr[NBMAX];
+    // Bounds for whole sample tiles, in the form of the linear rows (A, B, C): the tangent cone of the box's bounding
+    // sphere (a segment that misses it misses the box) and of its inscribed sphere (a segment that meets it meets the
+    // box).  A row whose cone form does not hold for this hit is +inf (outer: may always block) / -inf (inner: never
+    // known to block); a box this lane does not use has outer = -inf.
+    float ro[NBMAX][3], ri[NBMAX][3];
 };
 template <int NB>
 __device__ __forceinline__ void box_values(const BoxSet& bx, float ur, float vr, float (&val)[NB > 0 ? NB : 1]) {
@@ -633,7 +638,6 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     };
     // decided(i0,i1,j0,j1): false = undecided for some lane, true = decided for the whole wave (and accounted for)
     auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
-        if (NB > 0) return false;  // boxes have no tile bound here: every sample is tested
         const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
         const float va = fmaf((float)j0, cell, koff), vb = fmaf((float)j1, cell, koff);
         const float u2lo = ua * ub <= 0.f ? 0.f : fminf(ua * ua, ub * ub), u2hi = fmaxf(ua * ua, ub * ub);
@@ -646,9 +650,29 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
             const float bu0 = ua * Bd[e], bu1 = ub * Bd[e], cv0 = va * Cd[e], cv1 = vb * Cd[e];
             const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
             const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
+            // (an inert row, A = -inf, must come out as "cannot block": its margin stays finite)
+#ifdef RT_EXP_OLD_MARGIN
             const float margin = 1e-5f * (fabsf(Ad[e]) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+#else
+            const float margin = 1e-5f * (fminf(fabsf(Ad[e]), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+#endif
             can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
             must_block = must_block || lo > margin;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            {   // bounding sphere: can the box block anywhere in the tile?
+                const float bu0 = ua * bx.ro[b][1], bu1 = ub * bx.ro[b][1], cv0 = va * bx.ro[b][2], cv1 = vb * bx.ro[b][2];
+                const float hi = bx.ro[b][0] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
+                const float margin = 1e-5f * (fminf(fabsf(bx.ro[b][0]), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+                can_block = can_block || !(hi < -margin);
+            }
+            if (ALL_OPAQUE) {   // inscribed sphere: does it block everywhere in the tile?
+                const float bu0 = ua * bx.ri[b][1], bu1 = ub * bx.ri[b][1], cv0 = va * bx.ri[b][2], cv1 = vb * bx.ri[b][2];
+                const float lo = bx.ri[b][0] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
+                const float margin = 1e-5f * (fminf(fabsf(bx.ri[b][0]), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+                must_block = must_block || lo > margin;
+            }
         }
         if (ALL_OPAQUE) {
             if (__any(can_block && !must_block)) return false;
@@ -795,7 +819,13 @@ __device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, int l, int s
 }
 
 template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
-__global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k_shade_fast(ShadeArgs a) {
+#ifndef RT_LB_NOBOX
+#define RT_LB_NOBOX 3   // waves per SIMD the register budget is set for: 4 would spill ~250 bytes per lane and cost 25 % (measured)
+#endif
+#ifndef RT_LB_BOX
+#define RT_LB_BOX 2
+#endif
+__global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX)) void k_shade_fast(ShadeArgs a) {
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -1085,6 +1115,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? 3 : 4)) void k
                                 bx.lo[b][1] = used ? sf.a.y - P.y : 1e30f; bx.hi[b][1] = used ? sf.b.y - P.y : 1e30f;
                                 bx.lo[b][2] = used ? sf.a.z - P.z : 1e30f; bx.hi[b][2] = used ? sf.b.z - P.z : 1e30f;
                                 bx.tr[b] = used ? sf.transp : 1.f;
+                                // tile bounds: tangent cones of the bounding and of the inscribed sphere (same conditions as
+                                // for a sphere's linear row: hit point outside, every sample beyond the tangent length)
+                                const f3 ocb = P - F3(sf.c.x, sf.c.y, sf.c.z);
+                                const float d2b = dot(ocb, ocb), lminb = llen - rho;
+                                const float la = dot(lrel, ocb), lb = dot(right, ocb), lcc = dot(up, ocb);
+#pragma unroll
+                                for (int w = 0; w < 2; ++w) {
+                                    const float rr = w == 0 ? sf.c.w : sf.c.w * 0.5773f;   // |edge| * sqrt(3)/2 (plus margin), |edge| / 2 (minus margin)
+                                    const float cb = d2b - rr * rr;
+                                    const bool ok = used && cb >= 1e-3f * rr * rr && cb < 1e4f * rr * rr && lminb > 0.f && lminb * lminb > cb * 1.0002f;
+                                    const float kk = -__builtin_amdgcn_rsqf(cb);
+                                    float* row = w == 0 ? bx.ro[b] : bx.ri[b];
+                                    row[0] = ok ? la * kk : ((w == 0 && used) ? INFINITY : -INFINITY);
+                                    row[1] = ok ? lb * kk : 0.f;
+                                    row[2] = ok ? lcc * kk : 0.f;
+                                }
                             }
                         }
                         float sum;
@@ -1605,14 +1651,25 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     }
 }
 
+// workgroups of a persistent kernel that fit one CU at a time (the kernels pull their work from a shared counter, so
+// more would only queue behind the resident ones)
+template <typename K>
+static int resident_blocks_per_cu(K kernel) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, SHADE_BLOCK, 0) != hipSuccess || n < 1) n = 1;
+    return n > 8 ? 8 : n;
+}
+
 template <int SM>
-static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s, hipEvent_t after_main) {
+static void launch_small(const ShadeArgs& a, int n_cu, dim3 g, dim3 b, hipStream_t s, hipEvent_t after_main) {
+    static int occ[2][2] = {{0, 0}, {0, 0}};   // [has_box][all_opaque], filled on first use
+    int& o = occ[a.has_box ? 1 : 0][a.all_opaque ? 1 : 0];
     if (a.has_box) {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, true, SM>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_fast<false, true, SM>), g, b, 0, s, a);
+        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, true, SM>); hipLaunchKernelGGL((k_shade_fast<true, true, SM>), dim3(n_cu * o), b, 0, s, a); }
+        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, true, SM>); hipLaunchKernelGGL((k_shade_fast<false, true, SM>), dim3(n_cu * o), b, 0, s, a); }
     } else {
-        if (a.all_opaque) hipLaunchKernelGGL((k_shade_fast<true, false, SM>), g, b, 0, s, a);
-        else hipLaunchKernelGGL((k_shade_fast<false, false, SM>), g, b, 0, s, a);
+        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, false, SM>); hipLaunchKernelGGL((k_shade_fast<true, false, SM>), dim3(n_cu * o), b, 0, s, a); }
+        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, false, SM>); hipLaunchKernelGGL((k_shade_fast<false, false, SM>), dim3(n_cu * o), b, 0, s, a); }
     }
     if (after_main) (void)hipEventRecord(after_main, s);
     if (a.has_box) {
@@ -1627,16 +1684,16 @@ static void launch_small(const ShadeArgs& a, dim3 g, dim3 b, hipStream_t s, hipE
 // Scenes of up to 8 surfaces use the register-resident kernels at full occupancy, 9..16 surfaces the same kernels
 // with twice the per-surface registers (two waves per SIMD; a deferred item then has 16 bits for the light), larger
 // scenes the any-size kernel.
-void rt_launch_shade(const ShadeArgs& a, int blocks, hipStream_t s, hipEvent_t after_main) {
-    const dim3 g(blocks), b(SHADE_BLOCK);
+void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main) {
+    const dim3 g(n_cu * 4), b(SHADE_BLOCK);
     const int S = a.fp.n_surfaces;
     if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
         hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
         if (after_main) (void)hipEventRecord(after_main, s);
     } else if (S > SMALL_MAX) {
-        launch_small<16>(a, g, b, s, after_main);
+        launch_small<16>(a, n_cu, g, b, s, after_main);
     } else {
-        launch_small<SMALL_MAX>(a, g, b, s, after_main);
+        launch_small<SMALL_MAX>(a, n_cu, g, b, s, after_main);
     }
     hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
 }
