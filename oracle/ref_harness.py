@@ -47,20 +47,62 @@ def available() -> bool:
 _mods = None
 
 
+_REF_MODULES = ("utils", "material", "camera", "light", "scene_settings", "surfaces", "surfaces.sphere",
+                "surfaces.infinite_plane", "surfaces.cube", "ray_tracer")
+
+
 def load():
-    """Import the reference's modules (flat imports => its directory goes on sys.path)."""
+    """Import the reference's modules FROM SOURCE, under their own flat names, without leaving anything behind.
+
+    The reference uses flat imports (``from camera import Camera``), so its names have to resolve while it loads.  A
+    finder limited to exactly its module names serves them from ``REFERENCE_DIR`` for the duration of the load; the
+    loader compiles the ``.py`` text and never reads the tree's ``__pycache__`` (bytecode shipped with an untrusted
+    tree is not executed).  Afterwards the finder is removed, ``sys.path`` is untouched, and ``sys.modules`` gets back
+    whatever it held under those names (this repository has a ``ray_tracer`` of its own).
+    """
     global _mods
     if _mods is None:
         if not available():
             raise RuntimeError(f"reference tree not found at {REFERENCE_DIR}")
-        if REFERENCE_DIR not in sys.path:
-            sys.path.insert(0, REFERENCE_DIR)
-        import camera as ref_camera
-        import light as ref_light
-        import ray_tracer as ref_rt
-        import scene_settings as ref_scene
+        import importlib
+        import importlib.abc
+        import importlib.machinery
+        import importlib.util
 
-        _mods = {"rt": ref_rt, "camera": ref_camera, "light": ref_light, "scene": ref_scene}
+        class SourceOnlyLoader(importlib.machinery.SourceFileLoader):
+            def get_code(self, fullname):
+                path = self.get_filename(fullname)
+                with open(path, "rb") as f:
+                    return compile(f.read(), path, "exec", dont_inherit=True)
+
+        class Finder(importlib.abc.MetaPathFinder):
+            def find_spec(self, fullname, path=None, target=None):
+                if fullname not in _REF_MODULES:
+                    return None
+                rel = fullname.replace(".", os.sep)
+                pkg = os.path.join(REFERENCE_DIR, rel, "__init__.py")
+                if os.path.isfile(pkg):
+                    return importlib.util.spec_from_file_location(fullname, pkg, loader=SourceOnlyLoader(fullname, pkg),
+                                                                  submodule_search_locations=[os.path.dirname(pkg)])
+                src = os.path.join(REFERENCE_DIR, rel + ".py")
+                if os.path.isfile(src):
+                    return importlib.util.spec_from_file_location(fullname, src, loader=SourceOnlyLoader(fullname, src))
+                return None
+
+        saved = {name: sys.modules.pop(name) for name in _REF_MODULES if name in sys.modules}
+        finder = Finder()
+        sys.meta_path.insert(0, finder)
+        try:
+            ref_rt = importlib.import_module("ray_tracer")
+            loaded = {name: sys.modules[name] for name in _REF_MODULES if name in sys.modules}
+        finally:
+            sys.meta_path.remove(finder)
+            for name in _REF_MODULES:
+                sys.modules.pop(name, None)
+            sys.modules.update(saved)
+        for name, mod in loaded.items():
+            assert os.path.abspath(mod.__file__).startswith(os.path.abspath(REFERENCE_DIR) + os.sep), (name, mod.__file__)
+        _mods = {"rt": ref_rt, "camera": loaded["camera"], "light": loaded["light"], "scene": loaded["scene_settings"]}
     return _mods
 
 

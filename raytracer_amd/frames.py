@@ -11,6 +11,12 @@ PyTorch is plumbing here: pinned and device buffers, two streams, events.
 from __future__ import annotations
 
 
+def _add_stats(a, b):
+    if a is None or b is None:
+        return a if b is None else dict(b)
+    return {k: ([x + y for x, y in zip(v, b[k])] if isinstance(v, list) else v + b[k]) for k, v in a.items()}
+
+
 class FrameStream:
     """Ring of ``depth`` (device uint8 frame, pinned host frame) pairs.
 
@@ -23,6 +29,11 @@ class FrameStream:
 
     With the default ring of three, one frame renders, one is being copied and one is in the caller's hands.
     ``submit`` blocks only when the frame it returns has not reached the host yet.
+
+    Queued frames cannot grow the library's ray / shade queues (``rt_render_enqueue``), and a frame that outgrew them
+    would be incomplete.  The ray tree of a scene does not depend on the jitter seed, so the FIRST frame of every scene
+    goes through the synchronous entry point, which sizes the queues (and raises if that fails); the frames queued
+    after it have the same tree and fit.  ``stats()`` still reports an overflow the library saw, as an error.
     """
 
     def __init__(self, renderer, width, height, depth=3, flags=0):
@@ -45,6 +56,8 @@ class FrameStream:
         self.copied = [torch.cuda.Event() for _ in range(depth)]
         self.submitted = 0
         self.delivered = 0
+        self._sized_for = None      # scene the queues were last sized for by a synchronous frame
+        self._sync_stats = None     # statistics of the synchronous frames since the last stats()
 
     def _deliver(self):
         slot = self.delivered % self.depth
@@ -63,8 +76,15 @@ class FrameStream:
         if self.submitted >= self.depth:
             # the device frame of this slot is still the source of an earlier copy
             render_stream.wait_event(self.copied[slot])
-        self.r.enqueue_rows_device(self.W, self.H, 0, self.dev_frames[slot].data_ptr(), stream=render_stream.cuda_stream,
-                                   seed=seed, flags=self.flags)
+        if self._sized_for != self.r._scene_token:
+            # first frame of this scene: the synchronous call grows the queues to what the scene's ray tree needs
+            st = self.r.render_rows_device(self.W, self.H, 0, self.dev_frames[slot].data_ptr(), stream=render_stream.cuda_stream,
+                                           seed=seed, flags=self.flags)
+            self._sync_stats = _add_stats(self._sync_stats, st)
+            self._sized_for = self.r._scene_token
+        else:
+            self.r.enqueue_rows_device(self.W, self.H, 0, self.dev_frames[slot].data_ptr(), stream=render_stream.cuda_stream,
+                                       seed=seed, flags=self.flags)
         self.rendered[slot].record(render_stream)
         self.copy_stream.wait_event(self.rendered[slot])
         with torch.cuda.stream(self.copy_stream):
@@ -80,4 +100,6 @@ class FrameStream:
 
     def stats(self):
         """Summed statistics of the frames submitted since the last call (waits for them)."""
-        return self.r.wait()
+        st = _add_stats(self.r.wait(), self._sync_stats)
+        self._sync_stats = None
+        return st

@@ -84,6 +84,8 @@ def _stats_dict(st: packing.RtStats):
 class Renderer:
     """One GPU context (one ``rt_handle``): upload a scene once, render any number of frames."""
 
+    _scene_serial = 0
+
     def __init__(self, device=0):
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -116,7 +118,8 @@ class Renderer:
         packed = scene if isinstance(scene, packing.PackedScene) else packing.pack_scene(scene)
         self._check(self._lib.rt_set_scene(self._h, C.byref(packed.desc)))
         self._packed = packed
-        self._scene_token = id(scene)
+        Renderer._scene_serial += 1
+        self._scene_token = Renderer._scene_serial     # changes with every upload (frames.FrameStream sizes its queues per scene)
         return self
 
     def render_rows(self, width, height, *, seed=0, row_begin=0, row_end=None, stripe_rows=1, stripe_count=1,

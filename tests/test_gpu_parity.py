@@ -442,6 +442,37 @@ def test_frame_stream_delivers_every_frame_to_the_host_in_order(renderer):
         FrameStream(renderer, w, h, depth=9)
 
 
+def test_frame_stream_on_a_fresh_handle_with_a_deep_ray_tree(oracle, tmp_path):
+    """A handle that never rendered synchronously, and a scene whose ray tree outgrows the initial queues (transparency
+    scene with 9 levels): queued frames cannot grow the queues, so FrameStream sizes them with a synchronous first
+    frame -- every delivered frame is complete (counters and bytes equal the synchronous frames, which the oracle pins)."""
+    from raytracer_amd.frames import FrameStream
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scenes", "transparency_v7.txt")).read()
+    lines = [("set " + " ".join(l.split()[1:5]) + " 9") if l.startswith("set") else l for l in text.splitlines()]
+    sc = R.parse_scene_file(write_scene(tmp_path, "\n".join(lines) + "\n"))
+    w, h = 288, 288                                    # more than the queues' floor of 65536 pixels
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(sc)
+        fs = FrameStream(r, w, h, depth=3)
+        got = []
+        for s in range(4):
+            done = fs.submit(s)
+            if done is not None:
+                got.append(done.copy())
+        got += [d.copy() for d in fs.drain()]
+        st = fs.stats()
+        want = [r.render_rows(w, h, seed=s, want_f32=False) for s in range(4)]
+        assert st["shaded_points"] == sum(x[2]["shaded_points"] for x in want) and st["shaded_points"] > 4 * 4 * w * h
+        for (_, a, _), b in zip(want, got):
+            assert np.array_equal(a, b)
+        ref, cnt = oracle.render_frame(sc, w, h, seed=0, threads=THREADS)
+        assert_parity(got[0], ref)
+        assert counters_of(want[0][2]) == cnt
+    finally:
+        r.close()
+
+
 def test_two_pipelines_give_the_frames_of_one(renderer):
     """distributed.DistributedRenderer with two pipelines (two handles, two streams): queued frames alternate over
     them, overlap at their ends, and equal the frames of the synchronous call; statistics add up."""
