@@ -39,6 +39,7 @@ WORKLOADS = {
     "cubes_1080p": ("cubes", 1920, 1080),
     "v7_1080p": ("transparency_v7", 1920, 1080),
     "synthetic_4k": ("synthetic_10k_1k", 3840, 2160),
+    "spheres40_1080p": ("spheres_40", 1920, 1080),
 }
 
 
@@ -312,8 +313,8 @@ def main():
                              "note": "reference-equivalent flop (every N*N shadow ray against every surface, per-test costs fixed "
                                      "by convention) / isolated shading time: a speed-up over brute force, NOT a roofline fraction"},
                          "brute_force": brute,
-                         "note": "achieved = FP32 flop the kernel EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 "
-                                 "x 64 lanes, FMA = 2; counters collected on this build, see pmc_*) / the launch's duration measured "
+                         "note": "achieved = FP32 flop the kernel EXECUTED per launch (rocprofv3 SQ_INSTS_VALU_FLOPS_FP32 x 64 lanes: add / mul / "
+                                 "transcendental 1, fma 2, packed fma 4; counters collected on this build, see pmc_*) / the launch's duration measured "
                                  "live with HIP events on its own stream, running alone"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -37,10 +37,21 @@ def scene_path(name):
 _cache = {}
 
 
+PERTURB = 1e-13   # camera nudge of the "perturbed" renders (every component of the position)
+
+
 def _scene(name):
+    """Parsed scene; ``name#p`` = the same scene with the camera position nudged by PERTURB on every component (the
+    reference's own Camera constructor rebuilds the basis)."""
     from oracle import ref_harness as H
     if name not in _cache:
-        _cache[name] = H.parse(scene_path(name))
+        base = name.split("#")[0]
+        sc = H.parse(scene_path(base))
+        if name.endswith("#p"):
+            cam = sc.camera
+            sc.camera = type(cam)(np.asarray(cam.position, dtype=float) + PERTURB, cam.look_at, cam.up_vector,
+                                  cam.screen_distance, cam.screen_width)
+        _cache[name] = sc
     return _cache[name]
 
 
@@ -136,6 +147,32 @@ def item_sparse(pool, only):
                             rgb=rgb, width=W, height=Hh, seed=0,
                             counters=json.dumps(counters))
         print("sparse", key, counters, round(time.time() - t0, 1), "s", flush=True)
+
+
+def item_perturbed(pool, only):
+    """The oracle against itself: the frames and sparse pixel sets above once more, identical jitter, camera position
+    nudged by 1e-13.  Where the two renders differ the reference's own image hinges on float64 rounding noise (shadow
+    rays that start on the hit sphere: sign of |P-C|^2 - r^2), so this is the ceiling of any parity figure and the
+    mask of pixels on which a comparison is meaningful.  Stored as uint8 (np.uint8 truncation, as the goldens)."""
+    if only and "perturbed" not in only:
+        return
+    os.makedirs(os.path.join(GOLD, "perturbed"), exist_ok=True)
+    for name, W, Hh in [("pool", 500, 500), ("cubes", 480, 270), ("transparency_v7", 480, 270), ("transparency_original", 256, 256)]:
+        t0 = time.time()
+        xs = np.tile(np.arange(W), Hh)
+        ys = np.repeat(np.arange(Hh), W)
+        rgb, _, _ = parallel_pixels(pool, name + "#p", W, Hh, xs, ys, 0)
+        np.savez_compressed(os.path.join(GOLD, "perturbed", f"{name}_{W}x{Hh}_seed0.npz"), u8=np.uint8(rgb.reshape(Hh, W, 3)),
+                            nudge=PERTURB)
+        print("perturbed frame", name, round(time.time() - t0, 1), "s", flush=True)
+    for name, W, Hh, n in [("cubes", 1920, 1080, 2048), ("transparency_v7", 1920, 1080, 2048), ("pool", 3840, 2160, 1024),
+                           ("pool_n16", 3840, 2160, 768), ("synthetic_10k_1k", 3840, 2160, 384)]:
+        t0 = time.time()
+        xs, ys = sparse_pixels(W, Hh, n, salt=len(name) * 7919 + W)
+        rgb, _, _ = parallel_pixels(pool, name + "#p", W, Hh, xs, ys, 0, chunk=16 if "synthetic" in name else 64)
+        np.savez_compressed(os.path.join(GOLD, "perturbed", f"{name}_{W}x{Hh}.npz"), x=xs.astype(np.int32), y=ys.astype(np.int32),
+                            u8=np.uint8(rgb), nudge=PERTURB)
+        print("perturbed sparse", name, round(time.time() - t0, 1), "s", flush=True)
 
 
 def item_chain(pool, only):
@@ -281,7 +318,8 @@ def item_kat(pool, only):
     print("kat done", len(kinds), flush=True)
 
 
-ITEMS = {"kat": item_kat, "counters": item_counters, "chain": item_chain, "mt": item_mt, "sparse": item_sparse, "frames": item_frames}
+ITEMS = {"kat": item_kat, "counters": item_counters, "chain": item_chain, "mt": item_mt, "sparse": item_sparse, "frames": item_frames,
+         "perturbed": item_perturbed}
 
 
 def main():

@@ -93,7 +93,7 @@ struct rt_handle {
     MatF* d_mat = nullptr;
     LightF* d_light = nullptr;
     double* d_light64 = nullptr;         // float64 position xyz + radius per light (exact own-sphere evaluation)
-    unsigned long long* d_special = nullptr;  // per light: surfaces its centre lies on (ShadeArgs::special); null if none
+    uint32_t* d_special = nullptr;  // per light: surfaces its centre lies on (ShadeArgs::special); null if none
     int has_box = 0, all_opaque = 1;
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
@@ -801,10 +801,9 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_light64, light64.data(), sizeof(double) * light64.size(), hipMemcpyHostToDevice));
     int rc = build_grid(h, sd, S);
     if (rc != RT_OK) return rc;
-    // lights whose centre lies on a surface (ShadeArgs::special); scenes of up to 64 surfaces
-    if (S <= 64) {
-        std::vector<unsigned long long> special((size_t)std::max(L, 1), 0ull);
-        bool any = false;
+    // lights whose centre lies on a surface (ShadeArgs::special): L + 1 offsets, then the surfaces
+    {
+        std::vector<uint32_t> start((size_t)L + 1, 0u), items;
         for (int l = 0; l < L; ++l) {
             const double* q = d->light_param;
             const double p[3] = {q[0 * L + l], q[1 * L + l], q[2 * L + l]};
@@ -827,12 +826,14 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
                     }
                     dist = out2 > 0 ? std::sqrt(out2) : in_min;
                 }
-                if (dist <= tol) { special[l] |= 1ull << s2; any = true; }
+                if (dist <= tol) items.push_back((uint32_t)s2);
             }
+            start[(size_t)l + 1] = (uint32_t)items.size();
         }
-        if (any) {
-            HIP_TRY(h, hipMalloc(&h->d_special, sizeof(unsigned long long) * special.size()));
-            HIP_TRY(h, hipMemcpy(h->d_special, special.data(), sizeof(unsigned long long) * special.size(), hipMemcpyHostToDevice));
+        if (!items.empty()) {
+            start.insert(start.end(), items.begin(), items.end());
+            HIP_TRY(h, hipMalloc(&h->d_special, sizeof(uint32_t) * start.size()));
+            HIP_TRY(h, hipMemcpy(h->d_special, start.data(), sizeof(uint32_t) * start.size(), hipMemcpyHostToDevice));
         }
     }
     h->S = S; h->M = M; h->L = L; h->N = d->n_shadow; h->R = d->max_rec;

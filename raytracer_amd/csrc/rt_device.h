@@ -204,11 +204,12 @@ struct ShadeArgs {
     uint32_t* full_count; // RT_PAIR_FULL entries: they fill the same list from its END downwards (one lane each in k_shade_exact)
     uint32_t* work4;     // ... and their work counter
     float exact_min;     // a back-lit pair goes to k_shade_exact only if its specular term can exceed this (full scale = 1)
-    // Lights whose centre lies on (within 1e-3 of) a surface: bit s of special[l] names the surface (null: the scene has
-    // none; scenes of up to 64 surfaces only).  A shadow ray towards such a light meets that surface at t = dist up to
-    // rounding, and the reference decides t < dist by the last bit of its float64 arithmetic: every pair with such a
-    // light is shaded by k_shade_exact, with those surfaces tested in float64 (list entries with RT_PAIR_FULL set).
-    const unsigned long long* special;
+    // Lights whose centre lies on (within 1e-3 of) a surface (null: the scene has none): the surfaces of light l are
+    // special[L + 1 + k] for k in [special[l], special[l + 1]).  A shadow ray towards such a light meets that surface at
+    // t = dist up to rounding, and the reference decides t < dist by the last bit of its float64 arithmetic: every pair
+    // with such a light is shaded by k_shade_exact, with those surfaces tested in float64 (list entries with
+    // RT_PAIR_FULL set).
+    const uint32_t* special;
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;

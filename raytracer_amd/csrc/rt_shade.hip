@@ -275,12 +275,18 @@ __device__ __forceinline__ bool surface_blocks(const SurfF& sf, f3 P, f3 w, floa
 
 template <bool BATCH>
 __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, float dist, int own_id, f3 nrm, uint32_t flags,
-                                               unsigned long long reach_mask) {
+                                               unsigned long long reach_mask, const uint32_t* skip = nullptr, uint32_t n_skip = 0) {
     const SceneGrid& g = a.grid;
     float f = 1.f;
     // surfaces with the same geometry as the hit's own one (SurfF::pad names the first of them) start on the ray
     // origin just like it and follow the same rule
     const int own_grp = own_id >= 0 ? a.surf[own_id].pad : -1;
+    // surfaces the caller tests itself (scenes of more than 64 surfaces; smaller ones clear their bits in reach_mask)
+    auto skipped = [&](uint32_t j) -> bool {
+        bool sk = false;
+        for (uint32_t q = 0; q < n_skip; ++q) sk = sk || skip[q] == j;
+        return sk;
+    };
     if (!g.cell_start || a.fp.n_surfaces <= 64) {   // (a grid over so few surfaces only exists when a test forces it)
         const int S = a.fp.n_surfaces;
         if (S <= 64) {   // only the surfaces some lane of the wave can reach from this light (wave-uniform mask)
@@ -292,6 +298,7 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
             return f;
         }
         for (int s = 0; s < S; ++s) {
+            if (skipped((uint32_t)s)) continue;
             const SurfF sf = a.surf[s];
             f = surface_blocks<BATCH>(sf, P, w, dist, sf.pad == own_grp, nrm, flags) ? f * sf.transp : f;
         }
@@ -304,7 +311,7 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
     for (int k = 0; k < g.n_global; ++k) {
         const int j = (int)g.global_items[k];
         const SurfF sf = a.surf[j];
-        if (sf.pad == own_grp) continue;
+        if (sf.pad == own_grp || skipped((uint32_t)j)) continue;
         f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
     }
     if (f == 0.f) return f;
@@ -347,7 +354,7 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
             for (uint32_t q = p0; q < p1; ++q) seen = seen || g.items[q] == j;
             if (seen) continue;
             const SurfF sf = a.surf[j];
-            if (sf.pad == own_grp) continue;
+            if (sf.pad == own_grp || skipped(j)) continue;
             f = surface_blocks<BATCH>(sf, P, w, dist, false, nrm, flags) ? f * sf.transp : f;
         }
         if (f == 0.f) return f;
@@ -362,7 +369,13 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
 }
 
 __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio);
+__device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitRec& h, const SurfF& own_sf, bool own_valid, const LightF& lt,
+                                                  f3 lrel, float lc2, float linv, f3 right, f3 up, bool lit, unsigned long long reach_mask,
+                                                  uint32_t key, float& ratio, uint32_t& n_gen, int& n_rows);
 
+// LINEAR: scenes without a grid (17..64 surfaces) also try the linear rows of k_shade_fast per (wave, light); the grid
+// scenes' instance leaves that code out and keeps three waves per SIMD.
+template <bool LINEAR>
 __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t count = queue_slots(a.q);
     const int L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -372,6 +385,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
+    uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};   // (wave, light) pairs by class, as in k_shade_fast
 
     for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
         HitRec hr;
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         // with FP32 sums the pixel would carry that in its last FP32 bit (a byte flips when it sits on an integer).
         double cx = 0.0, cy = 0.0, cz = 0.0;
         for (int l = 0; l < L; ++l) {
-            if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
+            if (a.special && a.special[l] != a.special[l + 1]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
@@ -404,10 +418,11 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             const float lc2 = dot(lrel, lrel);
             const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
             const f3 ldir = lrel * linv;
-            float ratio;
+            float ratio = 1.f;
             if (lt.point_path) {
                 // ---- one ray to the light centre (ray_tracer.py:36-48)
                 n_samples += n_active;
+                if (LINEAR) wl_n[6] += 1;
                 const float dist = lc2 * linv;
                 ratio = shadow_factor<false>(a, P, ldir, dist, own_id, nrm, flags, ~0ull);
                 if (exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
@@ -419,20 +434,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 const f3 right = normalize(cross(ldir, perp));
                 const f3 up = normalize(cross(right, ldir));
                 const uint32_t key = rt_grid_key(a.fp.seed_key, gpix, node, (uint32_t)l);
-                // Scenes of 9..64 surfaces (no grid): which surfaces can any of the wave's 64 hits reach from this light at
+                // Scenes of 17..64 surfaces (no grid): which surfaces can any of the wave's 64 hits reach from this light at
                 // all?  All N*N samples lie within rho of the light centre, so a surface whose bounding sphere stays clear of
                 // the widened segment hit->light is skipped for the whole wave -- and a wave that reaches nothing skips the
                 // sample loop altogether (ratio = 1).  A light whose Phong terms vanish for a hit needs no surfaces for it.
                 unsigned long long reach_mask = ~0ull;
                 const int S = a.fp.n_surfaces;
+                bool linear_ok = false, linear_done = false, lit_lane = false;
                 if (!a.grid.cell_start && S <= 64 && !a.no_cull) {
                     reach_mask = 0ull;
+                    linear_ok = LINEAR && N < 256;
                     const float llen = lc2 * linv;
                     const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + llen);
                     const float inv_lc2 = linv * linv;
                     const float ndl0 = dot(nrm, ldir);
                     const float rv0 = 2.f * ndl0 * dot(nrm, view) - dot(ldir, view);
                     const bool lit = active && (ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f));
+                    lit_lane = lit;
                     for (int s = 0; s < S; ++s) {
                         const SurfF sf = a.surf[s];
                         bool reach;
@@ -477,6 +495,16 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         if (list && e0 + pre < a.exact_capacity) a.exact[e0 + pre] = make_uint2(base + lane, (uint32_t)l);
                     }
                 }
+                // 17..64 surfaces: the few surfaces in reach, as linear rows with sample-tile skipping (see k_shade_fast)
+                uint32_t n_gen = 0;
+                int n_rows = 0;
+                if (LINEAR && linear_ok && reach_mask && linear_wave_ratio(a, hr, own_sf, own_id >= 0, lt, lrel, lc2, linv, right, up, lit_lane,
+                                                                 reach_mask, key, ratio, n_gen, n_rows)) {
+                    n_samples += (unsigned long long)n_gen * n_active;
+                    reach_mask = 0ull;   // (done: the generic loop below is skipped, ratio is set)
+                    linear_done = true;
+                    wl_n[n_rows <= 4 ? n_rows : 4] += 1;
+                } else if (LINEAR) wl_n[reach_mask ? 5 : 0] += 1;
                 float sum = 0.f;
                 uint32_t s_idx = 0;
                 for (int i = 0; i < N && reach_mask; ++i) {
@@ -493,7 +521,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                         sum += shadow_factor<true>(a, P, w, dist, own_id, nrm, flags, reach_mask);
                     }
                 }
-                ratio = reach_mask ? sum * inv_n2 : 1.f;
+                if (!linear_done) ratio = reach_mask ? sum * inv_n2 : 1.f;
                 if (reach_mask) n_samples += (unsigned long long)(N * N) * n_active;
             }
             // ---- intensity (ray_tracer.py:105) and Phong terms (:157-170)
@@ -508,7 +536,12 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
             unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], cz);
         }
     }
-    if (lane == 0 && n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
+    if (lane == 0) {
+        if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+            if (LINEAR && wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
+    }
 }
 
 
@@ -818,6 +851,141 @@ __device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, int l, int s
     return !(dot(q, q) > lim * lim * 1.0003f);           // (NaN: true)
 }
 
+// The (wave, light) classification of k_shade_fast for scenes whose surfaces do not fit its register slots
+// (k_shade_general, no grid): the candidates are the surfaces of the wave's reach mask instead of all S.  With at
+// most KMAX of them, none a box some lane can reach, and every lane's tests NEVER or LINEAR, the wave's shadow ratio
+// comes from the compact sample loop (tile skipping included) and the function returns true; otherwise false, and
+// the caller runs its generic loop.  Conditions and margins are those of k_shade_fast, kept identical on purpose:
+// both were validated against the generic tests together.
+__device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitRec& h, const SurfF& own_sf, bool own_valid, const LightF& lt,
+                                                  f3 lrel, float lc2, float linv, f3 right, f3 up, bool lit, unsigned long long reach_mask,
+                                                  uint32_t key, float& ratio, uint32_t& n_gen, int& n_rows) {
+    const int n_reach = __popcll(reach_mask);
+    if (n_reach > KMAX) return false;
+    const int N = a.fp.n_shadow;
+    const f3 P = h.P;
+    const float llen = lc2 * linv;
+    const float rho_base = lt.radius * 0.70710678f * 1.0002f + 1e-6f;
+    const float rho = rho_base + fmaf(4e-7f, llen, 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z)));
+    const float inv_lc2 = linv * linv;
+    const float s_hi_scale = llen > 1.5f * rho ? 1.0002f / (llen - rho) : 1e30f;
+    const bool own_sphere = own_valid && own_sf.type == RT_SURF_SPHERE;
+    const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);
+    float A[KMAX + 1], B[KMAX + 1], C[KMAX + 1], tr[KMAX + 1];
+    bool gen = false;
+    uint32_t lin = 0;
+    unsigned long long rem = reach_mask;
+#pragma unroll
+    for (int e = 0; e < KMAX; ++e) {
+        A[e] = -INFINITY; B[e] = 0.f; C[e] = 0.f; tr[e] = 1.f;
+        if (e >= n_reach) continue;   // (wave-uniform)
+        const int s = (int)__builtin_ctzll(rem);
+        rem &= rem - 1ull;
+        const SurfF sf = a.surf[s];
+        tr[e] = sf.transp;
+        const bool own = own_valid && sf.pad == own_sf.pad;   // the own surface or a twin of it
+        if (sf.type == RT_SURF_SPHERE) {
+            const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
+            const float c = dot(oc, oc) - sf.a.w;
+            const float r = sf.c.x;
+            const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
+            const f3 q = oc + lrel * t;
+            const float reach = r + rho * fminf(1.f, s_hi_scale * (r + t * llen));
+            const bool never = own || !lit || dot(q, q) > reach * reach * 1.0002f;
+            if (!never) {
+                const float lmin = llen - rho;
+                const bool linear_ok = c >= 1e-3f * r * r && c < 1e4f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
+                if (!linear_ok) gen = true;
+                else {
+                    const float k = -__builtin_amdgcn_rsqf(c);
+                    A[e] = dot(lrel, oc) * k; B[e] = dot(right, oc) * k; C[e] = dot(up, oc) * k;
+                    lin |= 1u << e;
+                }
+            }
+        } else if (sf.type == RT_SURF_PLANE) {
+            const f3 n = F3(sf.a.x, sf.a.y, sf.a.z);
+            const float hh = sf.a.w - dot(P, n);
+            const float ah = fabsf(hh);
+            const float sg = hh < 0.f ? -1.f : 1.f;
+            const float dn0 = dot(lrel, n) * sg;
+            const bool never = own || !lit || (ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0));
+            if (!never) {
+                if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho) && ah > 64.f * (rho - rho_base))) gen = true;
+                else {
+                    A[e] = (dn0 - ah) * PLANE_SCALE; B[e] = dot(right, n) * (sg * PLANE_SCALE); C[e] = dot(up, n) * (sg * PLANE_SCALE);
+                    lin |= 1u << e;
+                }
+            }
+        } else if (lit) {
+            if (own) {
+                if (dot(lrel, h.nrm) - rho < 0.f) gen = true;   // some sample may enter the box
+            } else {
+                const f3 oc = P - F3(sf.c.x, sf.c.y, sf.c.z);   // bounding sphere
+                const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
+                const f3 q = oc + lrel * t;
+                const float reach = sf.c.w + rho;
+                if (!(dot(q, q) > reach * reach * 1.0002f)) gen = true;
+            }
+        }
+    }
+    A[KMAX] = -INFINITY; B[KMAX] = 0.f; C[KMAX] = 0.f; tr[KMAX] = own_sf.b.w;
+    if (own_sphere && !(h.flags & HF_CBATCH_POS) && lit) {   // the own sphere blocks a sample that enters it
+        const float r = own_sf.c.x;
+        const float dl = dot(lrel, ov);
+        if (dl - rho * r * 1.0002f < 0.f) {
+            if (llen - rho > 2.0002f * r) {
+                const float k = -2.0e6f;
+                A[KMAX] = dl * k; B[KMAX] = dot(right, ov) * k; C[KMAX] = dot(up, ov) * k;
+                lin |= 1u << KMAX;
+            } else gen = true;
+        }
+    }
+    if (__any(gen)) return false;
+    uint32_t cand = 0;
+#pragma unroll
+    for (int s = 0; s < KMAX + 1; ++s)
+        if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
+    const int k = __popc(cand);
+    if (k > KMAX) return false;
+    ratio = 1.f;
+    n_rows = k;
+    if (k == 0) return true;
+    float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
+    uint32_t crem = cand;
+#pragma unroll
+    for (int e = 0; e < KMAX; ++e) {
+        const int sl = crem ? (int)__builtin_ctz(crem) : -1;
+        crem &= crem - 1u;
+        Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
+        if (e >= k) continue;
+#pragma unroll
+        for (int t = 0; t < KMAX + 1; ++t)
+            if (sl == t) { Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t]; trd[e] = tr[t]; }
+    }
+    const float ku = RT_JITTER_INV * (1.0f / (float)N) * lt.radius;
+    const float koff = -0.5f * lt.radius;
+    BoxSet bx;
+    float sum;
+    const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
+    if (a.all_opaque) {
+        switch (kk) {
+            case 1: sum = compact_samples<1, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+        }
+    } else {
+        switch (kk) {
+            case 1: sum = compact_samples<1, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+        }
+    }
+    ratio = sum * (1.0f / (float)(N * N));
+    return true;
+}
+
 template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 #ifndef RT_LB_NOBOX
 #define RT_LB_NOBOX 3   // waves per SIMD the register budget is set for: 4 would spill ~250 bytes per lane and cost 25 % (measured)
@@ -915,7 +1083,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
 #else
         for (int l = 0; l < L; ++l) {
 #endif
-            if (a.special && a.special[l]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
+            if (a.special && a.special[l] != a.special[l + 1]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
@@ -1450,9 +1618,16 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
     const HitRec h = load_hit(a.q, slot);
     const f3 P = h.P;
     const uint32_t flags = h.flags;
-    const unsigned long long special = a.special[l];
+    const uint32_t* sp = a.special + a.fp.n_lights + 1 + a.special[l];   // the surfaces this light lies on
+    const uint32_t n_sp = a.special[l + 1] - a.special[l];
+    unsigned long long others = ~0ull;   // reach mask of the FP32 tests (scenes of up to 64 surfaces): all but those
+    bool on_own = false;
+    for (uint32_t k = 0; k < n_sp; ++k) {
+        if (sp[k] < 64u) others &= ~(1ull << sp[k]);
+        on_own = on_own || sp[k] == (uint32_t)h.own_id;
+    }
     const bool own_valid = !(flags & HF_NO_OWN);
-    const bool own_special = own_valid && ((special >> h.own_id) & 1ull);
+    const bool own_special = own_valid && on_own;
     const int own_id = (own_valid && !own_special) ? h.own_id : -1;   // a special own surface is tested like any other, in float64
     const SurfF own_sf = a.surf[h.own_id];
     const MatF m = a.mat[own_sf.mat];
@@ -1469,7 +1644,7 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
     float ratio;
     if (lt.point_path) {
         // ---- one ray to the light centre (ray_tracer.py:36-48)
-        float f = shadow_factor<false>(a, P, ldir, lc2 * linv, own_id, h.nrm, flags, ~special);
+        float f = shadow_factor<false>(a, P, ldir, lc2 * linv, own_id, h.nrm, flags, others, sp, n_sp);
         if (own_exact && (flags & HF_CDOT_POS) && dot(ldir, ov) < inward_limit &&
             rtx::own_sphere_blocks_centre(p64, light64, a.surf64[own_id]))
             f *= own_sf.b.w;
@@ -1477,8 +1652,8 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
         const rtx::e3 to_light = rtx::sub(rtx::E3(light64[0], light64[1], light64[2]), P64);
         const rtx::e3 d64 = rtx::normalize(to_light);
         const double dist64 = sqrt(rtx::dotb(to_light, to_light));
-        for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
-            const int s = (int)__builtin_ctzll(mm);
+        for (uint32_t k = 0; k < n_sp && f != 0.f; ++k) {
+            const int s = (int)sp[k];
             double t;
             if (rtx::scalar_t(a.surf64[s], P64, d64, t) && RT_EPS < t && t < dist64) f *= a.surf[s].transp;
         }
@@ -1502,7 +1677,7 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
             const float dinv = __frsqrt_rn(d2);
             const f3 w = sv * dinv;
             const float dist = d2 * dinv;
-            float f = shadow_factor<true>(a, P, w, dist, own_id, h.nrm, flags, ~special);
+            float f = shadow_factor<true>(a, P, w, dist, own_id, h.nrm, flags, others, sp, n_sp);
             if (own_exact && (flags & HF_CBATCH_POS) && dot(w, ov) < inward_limit) {
                 if (!have_os) { os = rtx::own_sphere_setup(p64, light64); have_os = true; }
                 if (rtx::own_sphere_blocks_sample(os, light64, a.surf64[own_id], N, inv_n64, i, j, ub, vb)) f *= own_sf.b.w;
@@ -1513,8 +1688,8 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
             // (A hit ON such a surface always takes the float64 test: FP32 has no rule for it here.)
             bool have_ray = false;
             rtx::e3 d64 = rtx::E3(0, 0, 1); double dist64 = 0;
-            for (unsigned long long mm = special; mm && f != 0.f; mm &= mm - 1ull) {
-                const int s = (int)__builtin_ctzll(mm);
+            for (uint32_t k = 0; k < n_sp && f != 0.f; ++k) {
+                const int s = (int)sp[k];
                 const SurfF sf = a.surf[s];
                 const bool own_here = own_special && sf.pad == own_sf.pad;
                 const bool b_short = surface_blocks<true>(sf, P, w, dist * 0.9998f, false, h.nrm, flags);
@@ -1688,7 +1863,12 @@ void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t aft
     const dim3 g(n_cu * 4), b(SHADE_BLOCK);
     const int S = a.fp.n_surfaces;
     if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
-        hipLaunchKernelGGL(k_shade_general, g, b, 0, s, a);
+#ifdef RT_EXP_NO_LINEAR_GENERAL   // timing experiment: reach mask only
+        if (false) {}
+#else
+        if (!a.grid.cell_start && S <= 64 && !a.no_cull) hipLaunchKernelGGL(k_shade_general<true>, g, b, 0, s, a);
+#endif
+        else hipLaunchKernelGGL(k_shade_general<false>, g, b, 0, s, a);
         if (after_main) (void)hipEventRecord(after_main, s);
     } else if (S > SMALL_MAX) {
         launch_small<16>(a, n_cu, g, b, s, after_main);

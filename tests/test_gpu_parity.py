@@ -745,7 +745,8 @@ def test_twelve_surfaces_use_the_wide_register_resident_kernels(renderer, oracle
         m = CI.metrics(np.uint8(ref), u8)
         assert m["pixels_beyond_1lsb"] == 0, (flags, m)
         classes[flags] = st["wave_light"]
-    assert sum(classes[0][:5]) > 0 and sum(classes[1][:7]) == 0     # classified by the fast kernel / not at all
+    assert sum(classes[0][:5]) > 0 and sum(classes[1][:5]) > 0      # classified by the fast kernel / by the any-size kernel
+    assert sum(classes[1][:6]) == sum(classes[0][:6])               # ... over the same (wave, light) pairs
     assert sum(classes[2][:5]) == 0 and classes[2][5] > 0           # brute force: every pair through the generic loop
 
 
@@ -786,6 +787,32 @@ def test_lights_on_a_ceiling_a_ball_and_a_box(renderer, oracle, tmp_path, n, rad
         m = CI.metrics(np.uint8(ref), u8)
         assert m["pixels_beyond_1lsb"] <= 1, (flags, m)
         assert st["wave_light"][7] >= 3 * st["shaded_points"] * 0.99     # every (hit, light) pair went the float64 way
+
+
+@pytest.mark.parametrize("n,radius,grid", [(1, 0.5, "auto"), (3, 1.0, "auto"), (3, 1.0, "0")])
+def test_lights_on_surfaces_of_a_crowded_scene(oracle, tmp_path, monkeypatch, n, radius, grid):
+    """The same with more than 64 surfaces (uniform grid, or every surface tested with RT_GRID=0): a lamp on the back
+    wall, one on a sphere in the crowd and one on a box face; the other light of the scene takes the ordinary path."""
+    monkeypatch.setenv("RT_GRID", grid)
+    text = _crowded_scene_text(60, 20, seed=9).replace("set 0.3 0.4 0.6 2 3", f"set 0.3 0.4 0.6 {n} 3")
+    text += ("sph 1.5 1 2 0.5 2\nbox -2 0.5 2 1 1\n"
+             f"lgt 0.5 3 -9  1 0.9 0.8  1 0.8 {radius}\n"         # on the wall z = -9
+             f"lgt 1.5 1.5 2  0.5 0.6 1  0.7 1 {radius}\n"         # on top of the added sphere
+             f"lgt -2 1 2  0.9 0.5 0.5  1 0.6 {radius}\n")         # on the top face of the added box
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    assert len(sc.surfaces) == 84 and len(sc.lights) == 5
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(sc)
+        w, h = 96, 64
+        ref, cnt = oracle.render_frame(sc, w, h, seed=6, threads=THREADS)
+        _, u8, st = r.render_rows(w, h, seed=6)
+        assert counters_of(st) == cnt
+        m = CI.metrics(np.uint8(ref), u8)
+        assert m["pixels_beyond_1lsb"] <= 1, m
+        assert st["wave_light"][7] >= 3 * st["shaded_points"] * 0.99     # three of the five lights went the float64 way
+    finally:
+        r.close()
 
 
 def test_pair_list_grows_when_every_hit_is_listed(oracle, tmp_path, monkeypatch):
@@ -866,3 +893,25 @@ def test_mid_size_scene_uses_the_reach_mask(renderer, oracle, tmp_path):
     assert counters_of(st) == cnt
     assert_parity(masked, ref)
     assert CI.metrics(brute, masked)["max_abs_diff"] <= 1
+
+
+@pytest.mark.parametrize("opaque", [False, True])
+def test_mid_size_scene_takes_linear_rows_and_skips_sample_tiles(renderer, oracle, tmp_path, opaque):
+    """40 surfaces, spheres and planes only, N = 10: most (wave, light) pairs reach a handful of surfaces, all of them
+    clear of the hit point, so the any-size kernel evaluates them as linear rows and decides whole sample tiles at once
+    (fewer samples generated than N * N per pair).  Image and counters as the oracle's and as RT_FLAG_NO_CULL's."""
+    text = _crowded_scene_text(38, 0, seed=11).replace("set 0.3 0.4 0.6 2 3", "set 0.3 0.4 0.6 10 3")
+    if opaque:
+        text = text.replace("  30 0.5", "  30 0").replace("  15 0.4", "  15 0")
+    sc = R.parse_scene_file(write_scene(tmp_path, text))
+    assert len(sc.surfaces) == 40
+    w, h = 128, 72
+    renderer.set_scene(sc)
+    ref, cnt = oracle.render_frame(sc, w, h, seed=4, threads=THREADS)
+    _, linear, st = renderer.render_rows(w, h, seed=4)
+    _, brute, st_b = renderer.render_rows(w, h, seed=4, flags=2)
+    assert counters_of(st) == cnt
+    assert_parity(linear, ref)
+    assert CI.metrics(brute, linear)["max_abs_diff"] <= 1
+    print("classes", st["wave_light"], st["shadow_samples"], st_b["shadow_samples"])
+    assert 0 < st["shadow_samples"] < 0.75 * st_b["shadow_samples"]

@@ -1,20 +1,71 @@
 #!/usr/bin/env python3
-"""Development probe (GPU box): parity figures against the committed reference goldens (frames and sparse pixels)."""
-import os, sys
+"""Parity report (GPU box): the HIP path, through the C ABI, against the committed reference goldens.
+
+    python tools/golden_report.py [out.json]        # default profiles/parity_r02.json
+
+Per comparison three figures, all "share of pixels within 1 LSB in every 8-bit channel":
+  raw      GPU vs the reference render (keyed jitter stream identical on both sides)
+  ceiling  the reference vs ITSELF with the camera position nudged by 1e-13 (tests/golden/perturbed/, made by
+           oracle/make_goldens.py in the build container): pixels where these two differ hinge on float64 rounding
+           noise in the reference (own-sphere shadow rays), no implementation can be asked to match them
+  stable   GPU vs the reference on the pixels where the two reference renders agree within 1 LSB
+Full frames at the resolutions the reference can render in minutes, and the reference's own pixels (sparse sets) of
+the benchmark configurations at their real resolutions.
+"""
+import json
+import os
+import sys
+
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
-from helpers import golden_npz, golden_png, scene
-from raytracer_amd import runtime, compare_images as CI
-r = runtime.Renderer(0)
-for name, w, h in [("pool", 500, 500), ("cubes", 480, 270), ("transparency_v7", 480, 270), ("transparency_original", 256, 256)]:
-    r.set_scene(scene(name))
-    _, u8, _ = r.render_rows(w, h, seed=0)
-    m = CI.metrics(golden_png(f"frames/{name}_{w}x{h}_seed0.png"), u8)
-    print(f"frame {name} {w}x{h}: {100 * m['within_1lsb']:.4f} % within 1 LSB, {m['pixels_beyond_1lsb']} beyond, max {m['max_abs_diff']}", flush=True)
-for key in ["cubes_1920x1080", "transparency_v7_1920x1080", "pool_3840x2160", "pool_n16_3840x2160", "synthetic_10k_1k_3840x2160"]:
-    z = golden_npz(f"sparse/{key}.npz")
-    r.set_scene(scene(key.rsplit("_", 1)[0]))
-    _, u8, _ = r.render_rows(int(z["width"]), int(z["height"]), seed=int(z["seed"]), want_f32=False)
-    m = CI.metrics(np.uint8(z["rgb"]), u8[z["y"], z["x"]])
-    print(f"sparse {key}: {len(z['x'])} pixels, {m['pixels_beyond_1lsb']} beyond 1 LSB, max {m['max_abs_diff']}", flush=True)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+from helpers import golden_npz, golden_png, scene  # noqa: E402
+from raytracer_amd import runtime  # noqa: E402
+
+
+def within(a, b):
+    """Per pixel: every channel within 1 LSB."""
+    return (np.abs(a.astype(np.int16) - b.astype(np.int16)) <= 1).all(axis=-1)
+
+
+def figures(gold, pert, gpu):
+    raw, ceil = within(gold, gpu), within(gold, pert)
+    stable = ceil
+    d = np.abs(gold.astype(np.int16) - gpu.astype(np.int16))
+    return {"pixels": int(raw.size),
+            "raw_within_1lsb": float(raw.mean()), "raw_beyond": int((~raw).sum()), "raw_max_abs_diff": int(d.max()),
+            "ceiling_within_1lsb": float(ceil.mean()), "ceiling_beyond": int((~ceil).sum()),
+            "ceiling_max_abs_diff": int(np.abs(gold.astype(np.int16) - pert.astype(np.int16)).max()),
+            "stable_pixels": int(stable.sum()),
+            "stable_within_1lsb": float(raw[stable].mean()) if stable.any() else None,
+            "stable_beyond": int((~raw[stable]).sum()),
+            "stable_max_abs_diff": int(d[stable].max()) if stable.any() else None}
+
+
+def main():
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "parity_r02.json")
+    r = runtime.Renderer(0)
+    report = {"bar": "share of pixels within 1 LSB per 8-bit channel; target >= 0.999 (raw)", "nudge": 1e-13, "frames": {}, "sparse": {}}
+    for name, w, h in [("pool", 500, 500), ("cubes", 480, 270), ("transparency_v7", 480, 270), ("transparency_original", 256, 256)]:
+        key = f"{name}_{w}x{h}_seed0"
+        r.set_scene(scene(name))
+        _, u8, _ = r.render_rows(w, h, seed=0, want_f32=False)
+        f = figures(golden_png(f"frames/{key}.png"), golden_npz(f"perturbed/{key}.npz")["u8"], u8)
+        report["frames"][key] = f
+        print("frame ", key, f, flush=True)
+    for key in ["cubes_1920x1080", "transparency_v7_1920x1080", "pool_3840x2160", "pool_n16_3840x2160", "synthetic_10k_1k_3840x2160"]:
+        z, zp = golden_npz(f"sparse/{key}.npz"), golden_npz(f"perturbed/{key}.npz")
+        assert np.array_equal(z["x"], zp["x"]) and np.array_equal(z["y"], zp["y"])
+        r.set_scene(scene(key.rsplit("_", 1)[0]))
+        _, u8, _ = r.render_rows(int(z["width"]), int(z["height"]), seed=int(z["seed"]), want_f32=False)
+        f = figures(np.uint8(z["rgb"]), zp["u8"], u8[z["y"], z["x"]])
+        report["sparse"][key] = f
+        print("sparse", key, f, flush=True)
+    with open(out_path, "w") as fh:
+        json.dump(report, fh, indent=1, sort_keys=True)
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ T="timeout -s KILL 240"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH2 > $OUT/trace.log 2>&1 || exit 1
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_isolated -- $BENCH > $OUT/trace_isolated.log 2>&1 || exit 1
 $T rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- $BENCH > $OUT/pmc_sq.log 2>&1 || exit 2
-$T rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_FMA_F64 --kernel-trace --output-format csv -d $OUT/pmc_class -- $BENCH > $OUT/pmc_class.log 2>&1 || exit 5
+$T rocprofv3 --pmc SQ_INSTS_VALU_FLOPS_FP32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_THREAD_CYCLES_VALU --kernel-trace --output-format csv -d $OUT/pmc_class -- $BENCH > $OUT/pmc_class.log 2>&1 || exit 5
 $T rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 3
 $T rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || exit 4
 echo done

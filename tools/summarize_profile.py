@@ -8,8 +8,10 @@ profiles/<tag>_<workload>_pmc.json (per-kernel averages of every counter collect
 profiles/shade_roofline.json, which bench.py reads: per workload, the dominant kernel's executed FP32 flop per
 launch, HBM bytes per launch and VALU issue figures, with the hash of the kernel sources they were collected on.
 
-Executed FP32 flop = 64 lanes x (SQ_INSTS_VALU_ADD_F32 + SQ_INSTS_VALU_MUL_F32 + SQ_INSTS_VALU_TRANS_F32
-+ 2 x SQ_INSTS_VALU_FMA_F32): wave-level instruction counts, every lane counted (an upper bound of the useful flop).
+Executed FP32 flop = 64 lanes x SQ_INSTS_VALU_FLOPS_FP32.  That counter adds, per wave-level instruction, 1 for
+v_add / v_mul / transcendental, 2 for v_fma / v_pk_add / v_pk_mul and 4 for v_pk_fma_f32 (calibrated on instruction
+streams of known length: tools/pmc_calibrate.sh, profiles/r02_pmc_calibration.txt); compares, min / max, conversions and
+integer work count nothing.  Every lane is counted (an upper bound of the useful flop).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size, so reads
 are doubled before being compared with byte counts.
 """
@@ -66,7 +68,7 @@ if shade:
     fetch, write, ms = g("FETCH_SIZE"), g("WRITE_SIZE"), g("ms_under_pmc")
     cyc = g("GRBM_GUI_ACTIVE") / 8.0          # the counter is summed over the 8 XCDs
     valu = g("SQ_INSTS_VALU")
-    flop = 64.0 * (g("SQ_INSTS_VALU_ADD_F32") + g("SQ_INSTS_VALU_MUL_F32") + g("SQ_INSTS_VALU_TRANS_F32") + 2.0 * g("SQ_INSTS_VALU_FMA_F32"))
+    flop = 64.0 * g("SQ_INSTS_VALU_FLOPS_FP32")
     entry = {
         "kernel": kname, "profile": f"{tag}_{wl}", "kernel_source_hash": kernel_source_hash(),
         "executed_fp32_flop_per_launch": flop,
@@ -74,7 +76,7 @@ if shade:
         "ms_under_pmc": ms,
         "counters": {n: g(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
                                        "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32",
-                                       "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_FMA_F64", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU",
+                                       "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_FLOPS_FP32", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU",
                                        "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE") if n in c},
         "valu_issue": {"cycles_per_valu_inst_per_simd": (cyc * 1024.0 / valu) if valu else None,
                        "effective_clock_ghz": (cyc / (ms * 1e-3) / 1e9) if ms else None,
