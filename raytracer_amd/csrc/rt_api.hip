@@ -44,7 +44,7 @@ constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
 constexpr int kAsyncDepth = 8;         // frames rt_render_enqueue keeps in flight
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
-constexpr int kQCounts = 48;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d
+constexpr int kQCounts = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 constexpr size_t kHostRows = 16384;    // rows of the pinned row-list staging buffer made at rt_create (grows on demand)
 
@@ -388,7 +388,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
-        sa.work = h->d_qcounts + 5; sa.work2 = h->d_qcounts + 6;
+        sa.work = h->d_qcounts + 64; sa.work2 = h->d_qcounts + 6;
         sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + 4;
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;

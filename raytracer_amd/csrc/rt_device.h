@@ -187,13 +187,15 @@ void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
 void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s);
 
 enum { SHADE_AUTO = 0, SHADE_GENERAL = 1 };
+#define RT_WORK_QUEUES 16u
+#define RT_WORK_QUEUE_STRIDE 32u   // words: one 128-byte line per counter
 struct ShadeArgs {
     FrameParams fp;
     int32_t variant;     // SHADE_AUTO picks the register-resident kernel for small scenes
     int32_t has_box;     // scene contains at least one box
     int32_t all_opaque;  // every surface's material has transparency == 0
     int32_t no_cull;     // 1: always run the generic per-sample loop (no per-light classification)
-    uint32_t* work;      // shared work counter of the fast kernel (zeroed per band)
+    uint32_t* work;      // work counters of the fast kernel: RT_WORK_QUEUES of them, RT_WORK_QUEUE_STRIDE words apart (zeroed per band)
     uint32_t* work2;     // shared work counter of the deferred kernel
     uint2* deferred;     // (first hit of a 64-hit chunk, light) pairs left to the generic loop
     uint32_t* deferred_count;

@@ -165,6 +165,23 @@ __device__ __forceinline__ bool box_blocks_a(const SurfF& s, f3 P, f3 w, float d
 
 __device__ __forceinline__ float3 ld3(const float* p) { return make_float3(p[0], p[1], p[2]); }
 
+// Read-only scene data at a wave-uniform address (a surface, a light): loaded through the constant address space, so the
+// compiler may use the scalar unit -- one s_load into SGPRs for the whole wave -- instead of a vector load that returns
+// the same 64 bytes to every lane's VGPRs.  (It cannot decide that on its own: the kernels also store to global memory,
+// and nothing tells it that those stores never alias the scene.)  The scene is uploaded before the launch.
+template <typename T>
+__device__ __forceinline__ T uniform_load(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    typedef const uint32_t __attribute__((address_space(4))) * const_words;
+    const const_words q = (const_words)(uintptr_t)p;
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = q[i];
+    T t;
+    __builtin_memcpy(&t, w, sizeof(T));
+    return t;
+}
+
 // two FP32 values in an aligned register pair: arithmetic on them is one packed instruction (v_pk_fma_f32 ...)
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 F2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
@@ -993,6 +1010,7 @@ template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 #ifndef RT_LB_BOX
 #define RT_LB_BOX 2
 #endif
+
 __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX)) void k_shade_fast(ShadeArgs a) {
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
@@ -1011,32 +1029,55 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
 #define STYPE(j) ((uint32_t)(tword >> (4 * (j))) & 0xFu)
 
-    // waves pull 4 x 64 hits at a time from a shared counter (classification makes the cost per hit
-    // uneven; one counter word sustains only ~90 atomics/us, hence the batch)
+    // Work item = one 64-hit chunk with all its lights (splitting a chunk by light was measured slower: the hit is loaded
+    // and its accumulators updated once per part, and more items mean more traffic on the work counters).  The cost per
+    // item is uneven (classification), so the waves pull items instead of owning them.  One counter word sustains only
+    // 50..90 atomics/us, which a small frame (one rank's share of a frame split over 8 GPUs: ~25k items, single grabs)
+    // would be bound by: the items are dealt into RT_WORK_QUEUES queues, each with a counter on a cache line of its own.
+    // A wave starts on the queue of its workgroup and moves on to the next queue when it finds one empty; a queue never
+    // refills, so a wave that has seen all of them empty is done.
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
-    // work item = one 64-hit chunk with all its lights (splitting a chunk by light was measured slower: the hit is
-    // loaded and its accumulators updated once per part, and short items saturate the shared work counter)
     const uint32_t n_items = (count + 63u) >> 6;
-    uint32_t grab = 0, grab_end = 0;
+    // (queue q owns the groups of 4 consecutive items q, q + Q, q + 2Q, ...: every queue covers the whole frame)
+    const uint32_t n_groups = (n_items + 3u) >> 2;
+    const uint32_t single_below = 16u * (n_waves / RT_WORK_QUEUES + 1u);   // single grabs once a queue holds fewer items than this
+    uint32_t queue = blockIdx.x % RT_WORK_QUEUES, queues_left = RT_WORK_QUEUES;
+    uint32_t grab = 0, grab_end = 0;   // positions within the queue
     for (;;) {
         if (grab >= grab_end) {
-            // batches of 4 while plenty of work is left, single items towards the end
-#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the shared work counter out of the picture
-            const uint32_t batch = RT_EXP_BATCH;
+            bool got = false;
+            while (queues_left) {
+                const uint32_t q_len = ((n_groups + RT_WORK_QUEUES - 1u - queue) / RT_WORK_QUEUES) << 2;
+                uint32_t g0 = 0xFFFFFFFFu, g1 = 0;
+                if (lane == 0 && q_len) {
+                    uint32_t* ctr = a.work + queue * RT_WORK_QUEUE_STRIDE;
+                    // (a plain look first: waves arriving at an empty queue do not queue up behind each other's atomics)
+                    const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (seen < q_len) {
+#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the work counters out of the picture
+                        const uint32_t batch = RT_EXP_BATCH;
 #else
-            const uint32_t batch = (grab_end + 16u * n_waves < n_items) ? 4u : 1u;
+                        const uint32_t batch = (seen + single_below < q_len) ? 4u : 1u;
 #endif
-            uint32_t g0 = 0;
-            if (lane == 0) g0 = atomicAdd(a.work, batch);
-            grab = __builtin_amdgcn_readfirstlane(g0);
-            grab_end = grab + batch;
-            if (grab >= n_items) break;
+                        g0 = atomicAdd(ctr, batch);
+                        g1 = g0 + batch;
+                    }
+                }
+                g0 = __builtin_amdgcn_readfirstlane(g0);
+                g1 = __builtin_amdgcn_readfirstlane(g1);
+                if (g0 < q_len) { grab = g0; grab_end = g1 < q_len ? g1 : q_len; got = true; break; }
+                queue = queue + 1u == RT_WORK_QUEUES ? 0u : queue + 1u;
+                queues_left -= 1u;
+            }
+            if (!got) break;
         }
-        const uint32_t item = grab;
+        const uint32_t item = (((grab >> 2) * RT_WORK_QUEUES + queue) << 2) | (grab & 3u);
         grab += 1u;
-        if (item >= n_items) { grab = grab_end; continue; }
-        const uint32_t base = item << 6;
+        if (item >= n_items) continue;   // (the frame's last group may be short)
+        const int l_first = 0, l_last = L;
+        const uint32_t chunk = item;
+        const uint32_t base = chunk << 6;
         HitRec h;
         bool active;
         if (!load_chunk(a.q, base, count, lane, h, active)) continue;
@@ -1081,13 +1122,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         cx = P.x; cy = P.y; cz = P.z;
         for (int l = 0; l < 0; ++l) {
 #else
-        for (int l = 0; l < L; ++l) {
+        for (int l = l_first; l < l_last; ++l) {
 #endif
             if (a.special && a.special[l] != a.special[l + 1]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
-            const LightF lt = a.light[l];
+            const LightF lt = uniform_load(a.light + l);
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? (1u << SM) - 1u : 0u;  // surfaces the generic loop has to test for this (wave, light)
             bool need_exact = false;                   // this lane's pair also goes to k_shade_exact (correction)
@@ -1114,14 +1155,34 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
                 const bool any_lit = __any(lit && active);   // a light behind every hit of the chunk: nothing to classify
-                float A[(SM + 1)], B[(SM + 1)], C[(SM + 1)];
+                // The rows some lane needs go straight into the compact arrays of the sample loop (slot k, wave-uniform;
+                // surfaces in ascending order, the own sphere last): a lane that does not need a row holds an inert one.
+                float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
+#pragma unroll
+                for (int e = 0; e < KMAX; ++e) { Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f; }
+                int k = 0;
+                auto append_row = [&](float ra, float rb, float rc, float rt) {
+                    switch (k) {
+                        case 0: Ad[0] = ra; Bd[0] = rb; Cd[0] = rc; trd[0] = rt; break;
+                        case 1: Ad[1] = ra; Bd[1] = rb; Cd[1] = rc; trd[1] = rt; break;
+                        case 2: Ad[2] = ra; Bd[2] = rb; Cd[2] = rc; trd[2] = rt; break;
+                        case 3: Ad[3] = ra; Bd[3] = rb; Cd[3] = rc; trd[3] = rt; break;
+                        case 4: Ad[4] = ra; Bd[4] = rb; Cd[4] = rc; trd[4] = rt; break;
+                        case 5: Ad[5] = ra; Bd[5] = rb; Cd[5] = rc; trd[5] = rt; break;
+                        case 6: Ad[6] = ra; Bd[6] = rb; Cd[6] = rc; trd[6] = rt; break;
+                        case 7: Ad[7] = ra; Bd[7] = rb; Cd[7] = rc; trd[7] = rt; break;
+                        default: break;   // more than KMAX rows: the pair is deferred (k > KMAX below)
+                    }
+                    k += 1;
+                };
                 bool gen = false;
-                uint32_t lin = 0, reach_bits = 0, box_bits = 0;
+                uint32_t reach_bits = 0, box_bits = 0;
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
-                    A[j] = -INFINITY; B[j] = 0.f; C[j] = 0.f;
                     if (j < S && any_lit && (!prefilter || ((premask >> (l * S + j)) & 1ull))) {   // (wave-uniform)
-                        const SurfF sf = a.surf[j];
+                        float ra = -INFINITY, rb = 0.f, rc = 0.f;
+                        bool lin_j = false;
+                        const SurfF sf = uniform_load(a.surf + j);
                         const bool own = own_valid && sf.pad == own_sf.pad;   // the own surface or a twin of it
                         if (STYPE(j) == RT_SURF_SPHERE) {
                             const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
@@ -1141,9 +1202,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 const bool linear_ok = c >= 1e-3f * r * r && c < 1e4f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
                                 if (!linear_ok) gen = true;
                                 else {
-                                    const float k = -__builtin_amdgcn_rsqf(c);
-                                    A[j] = dot(lrel, oc) * k; B[j] = dot(right, oc) * k; C[j] = dot(up, oc) * k;
-                                    lin |= 1u << j;
+                                    const float kk = -__builtin_amdgcn_rsqf(c);
+                                    ra = dot(lrel, oc) * kk; rb = dot(right, oc) * kk; rc = dot(up, oc) * kk;
+                                    lin_j = true;
                                 }
                             }
                         } else if (STYPE(j) == RT_SURF_PLANE) {
@@ -1157,8 +1218,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 reach_bits |= 1u << j;
                                 if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho) && ah > 64.f * (rho - rho_base))) gen = true;
                                 else {
-                                    A[j] = (dn0 - ah) * PLANE_SCALE; B[j] = dot(right, n) * (sg * PLANE_SCALE); C[j] = dot(up, n) * (sg * PLANE_SCALE);
-                                    lin |= 1u << j;
+                                    ra = (dn0 - ah) * PLANE_SCALE; rb = dot(right, n) * (sg * PLANE_SCALE); rc = dot(up, n) * (sg * PLANE_SCALE);
+                                    lin_j = true;
                                 }
                             }
                         } else {
@@ -1182,9 +1243,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 }
                             }
                         }
+                        if (__any(lin_j)) append_row(ra, rb, rc, ALL_OPAQUE ? 1.f : sf.transp);
                     }
                 }
-                A[SM] = -INFINITY; B[SM] = 0.f; C[SM] = 0.f;
                 // own sphere with c > 0 and a sample that may enter it steeply: k_shade_exact decides those samples in float64.
                 // Such a light lies behind the tangent plane (no diffuse term); when its specular term is below 1e-4 of
                 // full scale (0.03 LSB) for every channel, whatever the shadow ratio, the float64 answer cannot show.
@@ -1201,22 +1262,24 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                     }
                     need_exact = shows;
                 }
+                float own_a = -INFINITY, own_b = 0.f, own_c = 0.f;
+                bool own_lin = false;
+#ifdef RT_EXP_NO_OWN   // timing experiment: no own-sphere entry
+                if (false) {
+#else
                 if (own_sph_blocks && lit) {
+#endif
                     const float r = own_sf.c.x;
                     const float dl = dot(lrel, ov);
                     if (dl - rho * r * 1.0002f < 0.f) {  // some sample may enter the own sphere
                         if (llen - rho > 2.0002f * r) {
-                            const float k = -2.0e6f;      // far root -2 w.oc > 1e-6  <=>  -sv.oc * 2e6 > len
-                            A[SM] = dl * k; B[SM] = dot(right, ov) * k; C[SM] = dot(up, ov) * k;
-                            lin |= 1u << SM;
+                            const float kk = -2.0e6f;     // far root -2 w.oc > 1e-6  <=>  -sv.oc * 2e6 > len
+                            own_a = dl * kk; own_b = dot(right, ov) * kk; own_c = dot(up, ov) * kk;
+                            own_lin = true;
                         } else gen = true;
                     }
                 }
-                uint32_t cand = 0;
-#pragma unroll
-                for (int s = 0; s < (SM + 1); ++s)
-                    if (__ballot((lin >> s) & 1u)) cand |= 1u << s;
-                const int k = __popc(cand);
+                if (__any(own_lin)) append_row(own_a, own_b, own_c, ALL_OPAQUE ? 1.f : own_sf.b.w);
                 uint32_t bcand = 0;
                 if (HAS_BOX) {
 #pragma unroll
@@ -1246,24 +1309,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 if (!defer) {
                     wl_n[k + nb <= 4 ? k + nb : 4] += 1;
                     if (k + nb > 0) {
-                        // ---- compact the wave's candidate tests into register triples
-                        float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
-                        uint32_t rem = cand;
-#pragma unroll
-                        for (int e = 0; e < KMAX; ++e) {
-                            const int sl = rem ? (int)__builtin_ctz(rem) : -1;
-                            rem &= rem - 1u;
-                            Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
-                            if (e >= k) continue;   // (wave-uniform) only the first k entries are filled: the others stay inert
-#pragma unroll
-                            for (int t = 0; t < (SM + 1); ++t) {
-                                if (sl == t) {
-                                    Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t];
-                                    if (!ALL_OPAQUE && t < SM) trd[e] = a.surf[t < SM ? t : 0].transp;
-                                }
-                            }
-                            if (!ALL_OPAQUE && sl == SM) trd[e] = own_sf.b.w;
-                        }
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
                         const float ku = RT_JITTER_INV * invN * lt.radius;  // 2^-8 / N * radius
                         const float koff = -0.5f * lt.radius;
@@ -1278,7 +1323,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 // boxes out of reach stay inert: an empty box far away)
                                 const bool used = brem != 0u && ((box_bits >> sl) & 1u);
                                 brem &= brem - 1u;
-                                const SurfF sf = a.surf[sl];
+                                const SurfF sf = uniform_load(a.surf + sl);
                                 bx.lo[b][0] = used ? sf.a.x - P.x : 1e30f; bx.hi[b][0] = used ? sf.b.x - P.x : 1e30f;
                                 bx.lo[b][1] = used ? sf.a.y - P.y : 1e30f; bx.hi[b][1] = used ? sf.b.y - P.y : 1e30f;
                                 bx.lo[b][2] = used ? sf.a.z - P.z : 1e30f; bx.hi[b][2] = used ? sf.b.z - P.z : 1e30f;
@@ -1346,12 +1391,20 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
                 f3 term = F3(0.f, 0.f, 0.f);
+#ifdef RT_EXP_NO_PHONG   // timing experiment
+                term = F3(ratio, ratio, ratio);
+#else
                 phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+#endif
                 cx += (double)(h.wgt.x * term.x); cy += (double)(h.wgt.y * term.y); cz += (double)(h.wgt.z * term.z);
             }
         }
         if (active && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
             const uint32_t lp = h.lpix;
+#ifdef RT_EXP_NO_ATOMICS    // timing experiment: plain stores (wrong image)
+            a.accum[(size_t)0 * a.npix + lp] = cx; a.accum[(size_t)1 * a.npix + lp] = cy; a.accum[(size_t)2 * a.npix + lp] = cz;
+            continue;
+#endif
             unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], cx);
             unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], cy);
             unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], cz);
