@@ -309,14 +309,14 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
         if (S <= 64) {   // only the surfaces some lane of the wave can reach from this light (wave-uniform mask)
             for (unsigned long long m = reach_mask & (S == 64 ? ~0ull : (1ull << S) - 1ull); m; m &= m - 1ull) {
                 const int s = (int)__builtin_ctzll(m);
-                const SurfF sf = a.surf[s];
+                const SurfF sf = uniform_load(a.surf + s);
                 f = surface_blocks<BATCH>(sf, P, w, dist, sf.pad == own_grp, nrm, flags) ? f * sf.transp : f;
             }
             return f;
         }
         for (int s = 0; s < S; ++s) {
             if (skipped((uint32_t)s)) continue;
-            const SurfF sf = a.surf[s];
+            const SurfF sf = uniform_load(a.surf + s);
             f = surface_blocks<BATCH>(sf, P, w, dist, sf.pad == own_grp, nrm, flags) ? f * sf.transp : f;
         }
         return f;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
-            const LightF lt = a.light[l];
+            const LightF lt = uniform_load(a.light + l);
             const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
             const float lc2 = dot(lrel, lrel);
             const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                     const bool lit = active && (ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f));
                     lit_lane = lit;
                     for (int s = 0; s < S; ++s) {
-                        const SurfF sf = a.surf[s];
+                        const SurfF sf = uniform_load(a.surf + s);
                         bool reach;
                         if (sf.type == RT_SURF_PLANE) {
                             const f3 n = F3(sf.a.x, sf.a.y, sf.a.z);
@@ -660,9 +660,27 @@ __device__ __forceinline__ void box_values(const BoxSet& bx, float ur, float vr,
     }
 }
 
+// The linear rows of one (wave, light) pair as the packed sample loop wants them: (B, C) of a row in one register pair,
+// the A of rows 2e and 2e + 1 in another.  A lane that does not need a row holds an inert one (A = -inf, B = C = 0).
+struct Rows {
+    f2 BC[KMAX], AA[KMAX / 2];
+    float tr[KMAX];   // transparency of the row's surface (scenes with transparent surfaces)
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int e = 0; e < KMAX; ++e) { BC[e] = F2(0.f, 0.f); tr[e] = 1.f; }
+#pragma unroll
+        for (int e = 0; e < KMAX / 2; ++e) AA[e] = F2(-INFINITY, -INFINITY);
+    }
+    template <int E>
+    __device__ __forceinline__ void set(float a, float b, float c, float t) {
+        BC[E] = F2(b, c);
+        if (E & 1) AA[E >> 1].y = a; else AA[E >> 1].x = a;
+        tr[E] = t;
+    }
+};
+
 template <int K, int NB, bool ALL_OPAQUE>
-__device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const float (&Ad)[KMAX],
-                                                 const float (&Bd)[KMAX], const float (&Cd)[KMAX], const float (&tr)[KMAX],
+__device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const Rows& R,
                                                  const BoxSet& bx, uint32_t& n_generated) {
     // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
     // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
@@ -671,16 +689,16 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
     // at all (the jitter stream is keyed by the sample index, so skipping samples does not shift
     // the others).  With transparent surfaces only "nothing can block" decides a tile: a blocked
     // sample's factor depends on which entries block it.
-    constexpr int T1 = 8, T2 = 8;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
+#ifndef RT_T2
+#define RT_T2 8
+#endif
+    constexpr int T1 = 8, T2 = RT_T2;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
     const float cell = 256.0f * ku;    // width of one grid cell in ur / vr units
     uint32_t open_samples = 0;         // opaque scenes: samples nothing blocks
     float sum = 0.f;                   // otherwise: sum of the samples' light factors
-    // the rows as register pairs for the packed sample loop: (B, C) per row, the A of two rows share a pair
-    f2 BC[K > 0 ? K : 1], AA[K > 0 ? (K + 1) / 2 : 1];
-#pragma unroll
-    for (int e = 0; e < K; ++e) BC[e] = F2(Bd[e], Cd[e]);
-#pragma unroll
-    for (int e = 0; e < (K + 1) / 2; ++e) AA[e] = F2(Ad[2 * e], 2 * e + 1 < K ? Ad[2 * e + 1] : -INFINITY);
+    const f2 (&BC)[KMAX] = R.BC;
+    const f2 (&AA)[KMAX / 2] = R.AA;
+    const float (&tr)[KMAX] = R.tr;
     // row e for a pair of samples: A + ur * B + vr * C
     auto row_pair = [&](int e, f2 ur, f2 vr) -> f2 {
         const f2 t = (e & 1) ? pk_fma_bLcH(ur, BC[e], AA[e >> 1]) : pk_fma_bLcL(ur, BC[e], AA[e >> 1]);
@@ -697,14 +715,15 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         bool can_block = false, must_block = false;
 #pragma unroll
         for (int e = 0; e < K; ++e) {
-            const float bu0 = ua * Bd[e], bu1 = ub * Bd[e], cv0 = va * Cd[e], cv1 = vb * Cd[e];
-            const float hi = Ad[e] + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
-            const float lo = Ad[e] + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
+            const float Ae = (e & 1) ? AA[e >> 1].y : AA[e >> 1].x;
+            const float bu0 = ua * BC[e].x, bu1 = ub * BC[e].x, cv0 = va * BC[e].y, cv1 = vb * BC[e].y;
+            const float hi = Ae + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
+            const float lo = Ae + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
             // (an inert row, A = -inf, must come out as "cannot block": its margin stays finite)
 #ifdef RT_EXP_OLD_MARGIN
-            const float margin = 1e-5f * (fabsf(Ad[e]) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+            const float margin = 1e-5f * (fabsf(Ae) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
 #else
-            const float margin = 1e-5f * (fminf(fabsf(Ad[e]), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+            const float margin = 1e-5f * (fminf(fabsf(Ae), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
 #endif
             can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
             must_block = must_block || lo > margin;
@@ -898,7 +917,7 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
         if (e >= n_reach) continue;   // (wave-uniform)
         const int s = (int)__builtin_ctzll(rem);
         rem &= rem - 1ull;
-        const SurfF sf = a.surf[s];
+        const SurfF sf = uniform_load(a.surf + s);
         tr[e] = sf.transp;
         const bool own = own_valid && sf.pad == own_sf.pad;   // the own surface or a twin of it
         if (sf.type == RT_SURF_SPHERE) {
@@ -967,17 +986,28 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     ratio = 1.f;
     n_rows = k;
     if (k == 0) return true;
-    float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
+    Rows R;
+    R.clear();
     uint32_t crem = cand;
 #pragma unroll
     for (int e = 0; e < KMAX; ++e) {
         const int sl = crem ? (int)__builtin_ctz(crem) : -1;
         crem &= crem - 1u;
-        Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f;
         if (e >= k) continue;
+        float ra = -INFINITY, rb = 0.f, rc = 0.f, rt = 1.f;
 #pragma unroll
         for (int t = 0; t < KMAX + 1; ++t)
-            if (sl == t) { Ad[e] = A[t]; Bd[e] = B[t]; Cd[e] = C[t]; trd[e] = tr[t]; }
+            if (sl == t) { ra = A[t]; rb = B[t]; rc = C[t]; rt = tr[t]; }
+        switch (e) {   // (e is a constant after unrolling)
+            case 0: R.set<0>(ra, rb, rc, rt); break;
+            case 1: R.set<1>(ra, rb, rc, rt); break;
+            case 2: R.set<2>(ra, rb, rc, rt); break;
+            case 3: R.set<3>(ra, rb, rc, rt); break;
+            case 4: R.set<4>(ra, rb, rc, rt); break;
+            case 5: R.set<5>(ra, rb, rc, rt); break;
+            case 6: R.set<6>(ra, rb, rc, rt); break;
+            default: R.set<7>(ra, rb, rc, rt); break;
+        }
     }
     const float ku = RT_JITTER_INV * (1.0f / (float)N) * lt.radius;
     const float koff = -0.5f * lt.radius;
@@ -986,17 +1016,17 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
     if (a.all_opaque) {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, true>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
         }
     } else {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, false>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
         }
     }
     ratio = sum * (1.0f / (float)(N * N));
@@ -1012,6 +1042,10 @@ template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 #endif
 
 __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX)) void k_shade_fast(ShadeArgs a) {
+#ifdef RT_PARK
+    __shared__ float park[13 * SHADE_BLOCK];
+#define PARK(f) park[(f) * SHADE_BLOCK + threadIdx.x]
+#endif
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -1036,6 +1070,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     // would be bound by: the items are dealt into RT_WORK_QUEUES queues, each with a counter on a cache line of its own.
     // A wave starts on the queue of its workgroup and moves on to the next queue when it finds one empty; a queue never
     // refills, so a wave that has seen all of them empty is done.
+#ifdef RT_EXP_STAMPS
+    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define STAMP(i)
+#endif
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
     const uint32_t n_items = (count + 63u) >> 6;
@@ -1072,6 +1112,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             }
             if (!got) break;
         }
+        STAMP(0);   // (previous item's last light, accumulation and the grab)
         const uint32_t item = (((grab >> 2) * RT_WORK_QUEUES + queue) << 2) | (grab & 3u);
         grab += 1u;
         if (item >= n_items) continue;   // (the frame's last group may be short)
@@ -1083,7 +1124,28 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         if (!load_chunk(a.q, base, count, lane, h, active)) continue;
         const f3 P = h.P;
         const SurfF own_sf = a.surf[h.own_id];
+#ifdef RT_PARK
+        // What only the Phong terms need -- view direction, weight, material -- waits in LDS (one word per value and
+        // thread, read back per light): 13 registers less across the sample loops.
+        {
+            const MatF m0 = a.mat[own_sf.mat];
+            PARK(0) = h.view.x; PARK(1) = h.view.y; PARK(2) = h.view.z;
+            PARK(3) = h.wgt.x; PARK(4) = h.wgt.y; PARK(5) = h.wgt.z;
+            PARK(6) = m0.kd[0]; PARK(7) = m0.kd[1]; PARK(8) = m0.kd[2];
+            PARK(9) = m0.ks[0]; PARK(10) = m0.ks[1]; PARK(11) = m0.ks[2];
+            PARK(12) = m0.shin;
+        }
+#define H_VIEW F3(PARK(0), PARK(1), PARK(2))
+#define H_WGT F3(PARK(3), PARK(4), PARK(5))
+#define M_SHIN PARK(12)
+#define M_KS(c) PARK(9 + (c))
+#else
         const MatF m = a.mat[own_sf.mat];
+#define H_VIEW h.view
+#define H_WGT h.wgt
+#define M_SHIN m.shin
+#define M_KS(c) m.ks[c]
+#endif
         const bool own_valid = !(h.flags & HF_NO_OWN);
         const bool own_sphere = own_valid && own_sf.type == RT_SURF_SPHERE;
         const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);  // own sphere: oc
@@ -1117,6 +1179,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         premask = 0ull;
 #endif
 
+        STAMP(1);
         double cx = 0.0, cy = 0.0, cz = 0.0;   // lights summed in float64 (see k_shade_general)
 #ifdef RT_EXP_NO_LIGHTS     // timing experiment: load and accumulate only
         cx = P.x; cy = P.y; cz = P.z;
@@ -1128,6 +1191,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
+            STAMP(6);
             const LightF lt = uniform_load(a.light + l);
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? (1u << SM) - 1u : 0u;  // surfaces the generic loop has to test for this (wave, light)
@@ -1152,25 +1216,26 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 // towards the viewer) contributes exactly 0 whatever its shadow ratio: no surface
                 // is relevant for such a lane
                 const float ndl0 = dot(h.nrm, ldir);
-                const float rv0 = 2.f * ndl0 * dot(h.nrm, h.view) - dot(ldir, h.view);
-                const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
+                const f3 view0 = H_VIEW;
+                const float rv0 = 2.f * ndl0 * dot(h.nrm, view0) - dot(ldir, view0);
+                const bool lit = ndl0 > 0.f || (rv0 > 0.f || M_SHIN == 0.f);
                 const bool any_lit = __any(lit && active);   // a light behind every hit of the chunk: nothing to classify
+                STAMP(2);
                 // The rows some lane needs go straight into the compact arrays of the sample loop (slot k, wave-uniform;
                 // surfaces in ascending order, the own sphere last): a lane that does not need a row holds an inert one.
-                float Ad[KMAX], Bd[KMAX], Cd[KMAX], trd[KMAX];
-#pragma unroll
-                for (int e = 0; e < KMAX; ++e) { Ad[e] = -INFINITY; Bd[e] = 0.f; Cd[e] = 0.f; trd[e] = 1.f; }
+                Rows R;
+                R.clear();
                 int k = 0;
                 auto append_row = [&](float ra, float rb, float rc, float rt) {
                     switch (k) {
-                        case 0: Ad[0] = ra; Bd[0] = rb; Cd[0] = rc; trd[0] = rt; break;
-                        case 1: Ad[1] = ra; Bd[1] = rb; Cd[1] = rc; trd[1] = rt; break;
-                        case 2: Ad[2] = ra; Bd[2] = rb; Cd[2] = rc; trd[2] = rt; break;
-                        case 3: Ad[3] = ra; Bd[3] = rb; Cd[3] = rc; trd[3] = rt; break;
-                        case 4: Ad[4] = ra; Bd[4] = rb; Cd[4] = rc; trd[4] = rt; break;
-                        case 5: Ad[5] = ra; Bd[5] = rb; Cd[5] = rc; trd[5] = rt; break;
-                        case 6: Ad[6] = ra; Bd[6] = rb; Cd[6] = rc; trd[6] = rt; break;
-                        case 7: Ad[7] = ra; Bd[7] = rb; Cd[7] = rc; trd[7] = rt; break;
+                        case 0: R.set<0>(ra, rb, rc, rt); break;
+                        case 1: R.set<1>(ra, rb, rc, rt); break;
+                        case 2: R.set<2>(ra, rb, rc, rt); break;
+                        case 3: R.set<3>(ra, rb, rc, rt); break;
+                        case 4: R.set<4>(ra, rb, rc, rt); break;
+                        case 5: R.set<5>(ra, rb, rc, rt); break;
+                        case 6: R.set<6>(ra, rb, rc, rt); break;
+                        case 7: R.set<7>(ra, rb, rc, rt); break;
                         default: break;   // more than KMAX rows: the pair is deferred (k > KMAX below)
                     }
                     k += 1;
@@ -1195,17 +1260,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                             const f3 q = oc + lrel * t;
                             const float reach = r + rho * fminf(1.f, s_hi_scale * (r + t * llen));
                             const bool never = own || !lit || dot(q, q) > reach * reach * 1.0002f;
-                            if (!never) {
-                                reach_bits |= 1u << j;
+                            if (__any(!never)) {   // (wave-uniform; the lanes differ by selects only: no divergent branches)
                                 const float lmin = llen - rho;
                                 // (beyond ~100 radii the cone's opening is below what an FP32 cosine resolves)
                                 const bool linear_ok = c >= 1e-3f * r * r && c < 1e4f * r * r && lmin > 0.f && lmin * lmin > c * 1.0002f;
-                                if (!linear_ok) gen = true;
-                                else {
-                                    const float kk = -__builtin_amdgcn_rsqf(c);
-                                    ra = dot(lrel, oc) * kk; rb = dot(right, oc) * kk; rc = dot(up, oc) * kk;
-                                    lin_j = true;
-                                }
+                                const bool use = !never && linear_ok;
+                                const float kk = -__builtin_amdgcn_rsqf(c);
+                                reach_bits |= never ? 0u : 1u << j;
+                                gen = gen || (!never && !linear_ok);
+                                ra = use ? dot(lrel, oc) * kk : -INFINITY;
+                                rb = use ? dot(right, oc) * kk : 0.f;
+                                rc = use ? dot(up, oc) * kk : 0.f;
+                                lin_j = use;
                             }
                         } else if (STYPE(j) == RT_SURF_PLANE) {
                             const f3 n = F3(sf.a.x, sf.a.y, sf.a.z);
@@ -1214,13 +1280,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                             const float sg = hh < 0.f ? -1.f : 1.f;
                             const float dn0 = dot(lrel, n) * sg;  // > |h|  <=>  L is on the far side
                             const bool never = own || !lit || (ah - dn0) > rho * 1.0002f + 1e-5f * (ah + fabsf(dn0));
-                            if (!never) {
-                                reach_bits |= 1u << j;
-                                if (!(ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho) && ah > 64.f * (rho - rho_base))) gen = true;
-                                else {
-                                    ra = (dn0 - ah) * PLANE_SCALE; rb = dot(right, n) * (sg * PLANE_SCALE); rc = dot(up, n) * (sg * PLANE_SCALE);
-                                    lin_j = true;
-                                }
+                            if (__any(!never)) {
+                                const bool linear_ok = ah > 1e-4f && ah > RT_EPSF * 1.01f * (llen + rho) && ah > 64.f * (rho - rho_base);
+                                const bool use = !never && linear_ok;
+                                reach_bits |= never ? 0u : 1u << j;
+                                gen = gen || (!never && !linear_ok);
+                                ra = use ? (dn0 - ah) * PLANE_SCALE : -INFINITY;
+                                rb = use ? dot(right, n) * (sg * PLANE_SCALE) : 0.f;
+                                rc = use ? dot(up, n) * (sg * PLANE_SCALE) : 0.f;
+                                lin_j = use;
                             }
                         } else {
                             if (!lit) {
@@ -1256,12 +1324,15 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + rho))) {
                     bool shows = ndl0 > 0.f;
                     if (!shows) {
-                        const float sp = rv0 > 0.f ? pow_pos(rv0, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
-                        const float cmax = fmaxf(fmaxf(m.ks[0] * lt.col[0] * h.wgt.x, m.ks[1] * lt.col[1] * h.wgt.y), m.ks[2] * lt.col[2] * h.wgt.z);
+                        const float shin0 = M_SHIN;
+                        const f3 wgt0 = H_WGT;
+                        const float sp = rv0 > 0.f ? pow_pos(rv0, shin0) : (shin0 == 0.f ? 1.f : 0.f);
+                        const float cmax = fmaxf(fmaxf(M_KS(0) * lt.col[0] * wgt0.x, M_KS(1) * lt.col[1] * wgt0.y), M_KS(2) * lt.col[2] * wgt0.z);
                         shows = sp * lt.spec * lt.shadow * cmax > a.exact_min;
                     }
                     need_exact = shows;
                 }
+                STAMP(3);
                 float own_a = -INFINITY, own_b = 0.f, own_c = 0.f;
                 bool own_lin = false;
 #ifdef RT_EXP_NO_OWN   // timing experiment: no own-sphere entry
@@ -1346,39 +1417,41 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 }
                             }
                         }
+                        STAMP(4);
                         float sum;
                         uint32_t n_gen = 0;
                         if (!HAS_BOX || nb == 0) {
                             switch (k) {
-                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
                             }
                         } else {
                             // boxes: linear rows rounded up to 0 / 2 / 4 / 8 (spare rows are inert), boxes to 1 or NBMAX
                             const int kk = k == 0 ? 0 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
                             if (nb == 1) {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             } else {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
-                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, Ad, Bd, Cd, trd, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             }
                         }
                         ratio = sum * inv_n2;
+                        STAMP(5);
                         n_samples += (unsigned long long)n_gen * n_active;
                     }
                 }
@@ -1391,12 +1464,22 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
                 f3 term = F3(0.f, 0.f, 0.f);
+#ifdef RT_PARK
+                asm volatile("" ::: "memory");   // (read the parked values here, not before the sample loop)
+#endif
+                const f3 wgt1 = H_WGT;
 #ifdef RT_EXP_NO_PHONG   // timing experiment
                 term = F3(ratio, ratio, ratio);
 #else
-                phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+#ifdef RT_PARK
+                MatF m;
+                m.kd[0] = PARK(6); m.kd[1] = PARK(7); m.kd[2] = PARK(8);
+                m.ks[0] = PARK(9); m.ks[1] = PARK(10); m.ks[2] = PARK(11);
+                m.shin = PARK(12);
 #endif
-                cx += (double)(h.wgt.x * term.x); cy += (double)(h.wgt.y * term.y); cz += (double)(h.wgt.z * term.z);
+                phong_add(term, h.nrm, ldir, H_VIEW, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+#endif
+                cx += (double)(wgt1.x * term.x); cy += (double)(wgt1.y * term.y); cz += (double)(wgt1.z * term.z);
             }
         }
         if (active && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
@@ -1413,7 +1496,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 7; ++c)
+#ifdef RT_EXP_STAMPS   // timing experiment: the class counters report cycles per phase instead
+            if (c < 7) atomicAdd(&a.counters[CNT_WL_NONE + c], st_acc[c]);
+#else
             if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
+#endif
         if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
     }
 }
@@ -1465,7 +1552,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         const int own_id = (flags & HF_NO_OWN) ? -1 : h.own_id;
         const SurfF own_sf = a.surf[h.own_id];
         const MatF m = a.mat[own_sf.mat];
-        const LightF lt = a.light[l];
+        const LightF lt = uniform_load(a.light + l);
         const f3 lrel = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - P;
         const float lc2 = dot(lrel, lrel);
         const float linv = lc2 > 0.f ? __frsqrt_rn(lc2) : 0.f;
@@ -1483,7 +1570,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             const float dist = lc2 * linv;
             float f = 1.f;
             for (int s = 0; s < S; ++s) {
-                const SurfF sf = a.surf[s];
+                const SurfF sf = uniform_load(a.surf + s);
                 const bool own = own_id >= 0 && sf.pad == own_sf.pad;
                 bool blk;
                 if (sf.type == RT_SURF_SPHERE) blk = sphere_blocks_a(sf, P, ldir, dist, own, flags);
@@ -1503,7 +1590,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
 #pragma unroll
                 for (int c = 0; c < (HAS_BOX ? 6 : 4); ++c) g[j][c] = 0.f;
                 if (j < S) {
-                    const SurfF sf = a.surf[j];
+                    const SurfF sf = uniform_load(a.surf + j);
                     const bool own = own_id >= 0 && sf.pad == own_sf.pad;
                     if (STYPE(j) == RT_SURF_SPHERE) {
                         const f3 oc = P - F3(sf.a.x, sf.a.y, sf.a.z);
