@@ -385,6 +385,62 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
     return f;
 }
 
+// Work distribution of the persistent shading kernels.  Work item = one 64-hit chunk with all its lights (splitting chunks
+// by light was measured slower, for all chunks and for the last few thousand of a launch alike: the hit is loaded, the
+// chunk pre-tested and the accumulators updated once per part, and more items mean more traffic on the work counters).
+// The cost per item is uneven (classification), so the waves pull items instead of owning them.  One counter word
+// sustains only 50..90 atomics/us, which a small frame (one rank's share of a frame split over 8 GPUs: ~25k items,
+// single grabs) would be bound by: the items are dealt into RT_WORK_QUEUES queues, each with a counter on a cache line
+// of its own (queue q owns the groups of 4 consecutive items q, q + Q, q + 2Q, ...: every queue covers the whole frame).
+// A wave starts on the queue of its workgroup and moves on to the next queue when it finds one empty; a queue never
+// refills, so a wave that has seen all of them empty is done.  All values are wave-uniform.
+struct ItemQueues {
+    uint32_t n_items, n_groups, single_below, queue, queues_left, grab, grab_end;
+    __device__ __forceinline__ void init(uint32_t items, uint32_t n_waves) {
+        n_items = items;
+        n_groups = (items + 3u) >> 2;
+        single_below = 16u * (n_waves / RT_WORK_QUEUES + 1u);   // single grabs once a queue holds fewer items than this
+        queue = blockIdx.x % RT_WORK_QUEUES;
+        queues_left = RT_WORK_QUEUES;
+        grab = 0; grab_end = 0;   // positions within the queue
+    }
+    // the next item of this wave; false: every queue is empty
+    __device__ __forceinline__ bool next(uint32_t* work, uint32_t lane, uint32_t& item) {
+        for (;;) {
+            if (grab >= grab_end) {
+                bool got = false;
+                while (queues_left) {
+                    const uint32_t q_len = ((n_groups + RT_WORK_QUEUES - 1u - queue) / RT_WORK_QUEUES) << 2;
+                    uint32_t g0 = 0xFFFFFFFFu, g1 = 0;
+                    if (lane == 0 && q_len) {
+                        uint32_t* ctr = work + queue * RT_WORK_QUEUE_STRIDE;
+                        // (a plain look first: waves arriving at an empty queue do not queue up behind each other's atomics)
+                        const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen < q_len) {
+#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the work counters out of the picture
+                            const uint32_t batch = RT_EXP_BATCH;
+#else
+                            const uint32_t batch = (seen + single_below < q_len) ? 4u : 1u;
+#endif
+                            g0 = atomicAdd(ctr, batch);
+                            g1 = g0 + batch;
+                        }
+                    }
+                    g0 = __builtin_amdgcn_readfirstlane(g0);
+                    g1 = __builtin_amdgcn_readfirstlane(g1);
+                    if (g0 < q_len) { grab = g0; grab_end = g1 < q_len ? g1 : q_len; got = true; break; }
+                    queue = queue + 1u == RT_WORK_QUEUES ? 0u : queue + 1u;
+                    queues_left -= 1u;
+                }
+                if (!got) return false;
+            }
+            item = (((grab >> 2) * RT_WORK_QUEUES + queue) << 2) | (grab & 3u);
+            grab += 1u;
+            if (item < n_items) return true;   // (the frame's last group may be short)
+        }
+    }
+};
+
 __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio);
 __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitRec& h, const SurfF& own_sf, bool own_valid, const LightF& lt,
                                                   f3 lrel, float lc2, float linv, f3 right, f3 up, bool lit, unsigned long long reach_mask,
@@ -399,12 +455,15 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
     const float invN = 1.0f / (float)N;
     const float inv_n2 = 1.0f / (float)(N * N);
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * SHADE_BLOCK + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};   // (wave, light) pairs by class, as in k_shade_fast
 
-    for (uint32_t base = wave * 64; base < count; base += n_waves * 64) {
+    ItemQueues items;
+    items.init((count + 63u) >> 6, n_waves);
+    uint32_t item;
+    while (items.next(a.work, lane, item)) {
+        const uint32_t base = item << 6;
         HitRec hr;
         bool active;
         if (!load_chunk(a.q, base, count, lane, hr, active)) continue;
@@ -1063,13 +1122,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
 #define STYPE(j) ((uint32_t)(tword >> (4 * (j))) & 0xFu)
 
-    // Work item = one 64-hit chunk with all its lights (splitting a chunk by light was measured slower: the hit is loaded
-    // and its accumulators updated once per part, and more items mean more traffic on the work counters).  The cost per
-    // item is uneven (classification), so the waves pull items instead of owning them.  One counter word sustains only
-    // 50..90 atomics/us, which a small frame (one rank's share of a frame split over 8 GPUs: ~25k items, single grabs)
-    // would be bound by: the items are dealt into RT_WORK_QUEUES queues, each with a counter on a cache line of its own.
-    // A wave starts on the queue of its workgroup and moves on to the next queue when it finds one empty; a queue never
-    // refills, so a wave that has seen all of them empty is done.
 #ifdef RT_EXP_STAMPS
     unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
@@ -1078,44 +1130,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
 #endif
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
-    const uint32_t n_items = (count + 63u) >> 6;
-    // (queue q owns the groups of 4 consecutive items q, q + Q, q + 2Q, ...: every queue covers the whole frame)
-    const uint32_t n_groups = (n_items + 3u) >> 2;
-    const uint32_t single_below = 16u * (n_waves / RT_WORK_QUEUES + 1u);   // single grabs once a queue holds fewer items than this
-    uint32_t queue = blockIdx.x % RT_WORK_QUEUES, queues_left = RT_WORK_QUEUES;
-    uint32_t grab = 0, grab_end = 0;   // positions within the queue
+    ItemQueues items;
+    items.init((count + 63u) >> 6, n_waves);
     for (;;) {
-        if (grab >= grab_end) {
-            bool got = false;
-            while (queues_left) {
-                const uint32_t q_len = ((n_groups + RT_WORK_QUEUES - 1u - queue) / RT_WORK_QUEUES) << 2;
-                uint32_t g0 = 0xFFFFFFFFu, g1 = 0;
-                if (lane == 0 && q_len) {
-                    uint32_t* ctr = a.work + queue * RT_WORK_QUEUE_STRIDE;
-                    // (a plain look first: waves arriving at an empty queue do not queue up behind each other's atomics)
-                    const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (seen < q_len) {
-#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the work counters out of the picture
-                        const uint32_t batch = RT_EXP_BATCH;
-#else
-                        const uint32_t batch = (seen + single_below < q_len) ? 4u : 1u;
-#endif
-                        g0 = atomicAdd(ctr, batch);
-                        g1 = g0 + batch;
-                    }
-                }
-                g0 = __builtin_amdgcn_readfirstlane(g0);
-                g1 = __builtin_amdgcn_readfirstlane(g1);
-                if (g0 < q_len) { grab = g0; grab_end = g1 < q_len ? g1 : q_len; got = true; break; }
-                queue = queue + 1u == RT_WORK_QUEUES ? 0u : queue + 1u;
-                queues_left -= 1u;
-            }
-            if (!got) break;
-        }
         STAMP(0);   // (previous item's last light, accumulation and the grab)
-        const uint32_t item = (((grab >> 2) * RT_WORK_QUEUES + queue) << 2) | (grab & 3u);
-        grab += 1u;
-        if (item >= n_items) continue;   // (the frame's last group may be short)
+        uint32_t item;
+        if (!items.next(a.work, lane, item)) break;
         const int l_first = 0, l_last = L;
         const uint32_t chunk = item;
         const uint32_t base = chunk << 6;

@@ -12,9 +12,10 @@ from raytracer_amd.distributed import stripe_rows_for, max_rows_per_rank, concur
 
 W, H = 3840, 2160
 scene = R.parse_scene_file("scenes/pool_n16.txt")
-worlds = [int(a) for a in sys.argv[1:]] or [1, 8]
+one_lane = "--one-lane" in sys.argv
+worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]
 K = 24
-for lanes in (1, 2, 3, 4):
+for lanes in ((1,) if one_lane else (1, 2, 3, 4)):
     rs = [runtime.Renderer(0) for _ in range(lanes)]
     for r in rs:
         r.set_scene(scene)
