@@ -52,6 +52,10 @@ def main():
         r.set_scene(scene(name))
         _, u8, _ = r.render_rows(w, h, seed=0, want_f32=False)
         f = figures(golden_png(f"frames/{key}.png"), golden_npz(f"perturbed/{key}.npz")["u8"], u8)
+        # the same frame with every shadow ray tested against every surface in its generic FP32 form (RT_FLAG_NO_CULL):
+        # what remains there does not come from the classification, the linear rows or the tile decisions
+        _, brute, _ = r.render_rows(w, h, seed=0, want_f32=False, flags=2)
+        f["generic_tests_raw_beyond"] = int((~within(golden_png(f"frames/{key}.png"), brute)).sum())
         report["frames"][key] = f
         print("frame ", key, f, flush=True)
     for key in ["cubes_1920x1080", "transparency_v7_1920x1080", "pool_3840x2160", "pool_n16_3840x2160", "synthetic_10k_1k_3840x2160"]:
