@@ -229,10 +229,7 @@ def item_kat(pool, only):
         return
     from oracle import ref_harness as H
     m = H.load()
-    import importlib
-    sph_mod = importlib.import_module("surfaces.sphere")
-    pln_mod = importlib.import_module("surfaces.infinite_plane")
-    box_mod = importlib.import_module("surfaces.cube")
+    sph_mod, pln_mod, box_mod = m["sphere"], m["plane"], m["cube"]
     os.makedirs(os.path.join(GOLD, "kat"), exist_ok=True)
     rng = np.random.default_rng(20260101)
     n = 600

@@ -102,7 +102,8 @@ def load():
             sys.modules.update(saved)
         for name, mod in loaded.items():
             assert os.path.abspath(mod.__file__).startswith(os.path.abspath(REFERENCE_DIR) + os.sep), (name, mod.__file__)
-        _mods = {"rt": ref_rt, "camera": loaded["camera"], "light": loaded["light"], "scene": loaded["scene_settings"]}
+        _mods = {"rt": ref_rt, "camera": loaded["camera"], "light": loaded["light"], "scene": loaded["scene_settings"],
+                 "sphere": loaded["surfaces.sphere"], "plane": loaded["surfaces.infinite_plane"], "cube": loaded["surfaces.cube"]}
     return _mods
 
 

@@ -145,6 +145,8 @@ struct FrameParams {
 __host__ __device__ inline uint32_t rt_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x;
 }
+// hash of a pair counter (the keys are full rt_mix32 outputs: one round is enough for jitter)
+__host__ __device__ inline uint32_t rt_pair_hash(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; return x; }
 __host__ __device__ inline uint32_t rt_seed_key(uint32_t seed) { return rt_mix32(seed + 0x9E3779B9u); }
 __host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixel, uint32_t node, uint32_t light) {
     uint32_t k = rt_mix32(seed_key ^ pixel);
@@ -160,7 +162,7 @@ __host__ __device__ inline uint32_t rt_pair_counter(uint32_t key, uint32_t n, ui
     return key + (i * ((n + 1u) >> 1) + q) * 0x9E3779B9u;
 }
 __host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t n, uint32_t i, uint32_t j, uint32_t& u, uint32_t& v) {
-    const uint32_t m = rt_mix32(rt_pair_counter(key, n, i, j >> 1));
+    const uint32_t m = rt_pair_hash(rt_pair_counter(key, n, i, j >> 1));
     if (j & 1u) { u = (m >> 8) & 0xFFu; v = m & 0xFFu; }
     else { u = m >> 24; v = (m >> 16) & 0xFFu; }
 }

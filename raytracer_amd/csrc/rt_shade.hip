@@ -842,7 +842,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                         f2 vcol = vcol0;
                         float row_sum = 0.f;
                         for (int j = j0; j < j1; j += 2) {
-                            const uint32_t mm = rt_mix32(ctr);
+                            const uint32_t mm = rt_pair_hash(ctr);
                             ctr += 0x9E3779B9u;
                             const f2 ub = F2(ubyte_f32<3>(mm), ubyte_f32<1>(mm));
                             const f2 vb = F2(ubyte_f32<2>(mm), ubyte_f32<0>(mm));
@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                 const float cu = ((float)i * invN - 0.5f) * lt.radius;
                 uint32_t mm = 0;
                 for (int j = 0; j < N; ++j) {
-                    if (!(j & 1)) mm = rt_mix32(rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j >> 1));   // one hash per two samples
+                    if (!(j & 1)) mm = rt_pair_hash(rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j >> 1));   // one hash per two samples
                     const uint32_t ub = (j & 1) ? (mm >> 8) & 0xFFu : mm >> 24;
                     const uint32_t vb = (j & 1) ? mm & 0xFFu : (mm >> 16) & 0xFFu;
                     const float cv = ((float)j * invN - 0.5f) * lt.radius;

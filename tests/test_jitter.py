@@ -25,7 +25,7 @@ def test_two_neighbours_of_a_row_share_one_hash():
     for n in (1, 2, 5, 16):
         for i in range(n):
             for q in range((n + 1) // 2):
-                m = jitter.mix32(key + (i * ((n + 1) // 2) + q) * jitter.GOLDEN)
+                m = jitter.pair_hash(key + (i * ((n + 1) // 2) + q) * jitter.GOLDEN)
                 assert jitter.sample_bits(key, n, i * n + 2 * q) == (m >> 24, (m >> 16) & 255)
                 if 2 * q + 1 < n:
                     assert jitter.sample_bits(key, n, i * n + 2 * q + 1) == ((m >> 8) & 255, m & 255)
