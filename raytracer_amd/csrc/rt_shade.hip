@@ -779,11 +779,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
             const float hi = Ae + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
             const float lo = Ae + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
             // (an inert row, A = -inf, must come out as "cannot block": its margin stays finite)
-#ifdef RT_EXP_OLD_MARGIN
-            const float margin = 1e-5f * (fabsf(Ae) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
-#else
             const float margin = 1e-5f * (fminf(fabsf(Ae), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
-#endif
             can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
             must_block = must_block || lo > margin;
         }
@@ -1101,10 +1097,6 @@ template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 #endif
 
 __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX)) void k_shade_fast(ShadeArgs a) {
-#ifdef RT_PARK
-    __shared__ float park[13 * SHADE_BLOCK];
-#define PARK(f) park[(f) * SHADE_BLOCK + threadIdx.x]
-#endif
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -1122,6 +1114,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
 #define STYPE(j) ((uint32_t)(tword >> (4 * (j))) & 0xFu)
 
+#ifdef RT_EXP_SPAN
+    const unsigned long long span_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long span_item_max = 0, span_item_begin = span_begin;
+#endif
 #ifdef RT_EXP_STAMPS
     unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
 #define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
@@ -1134,8 +1130,17 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     items.init((count + 63u) >> 6, n_waves);
     for (;;) {
         STAMP(0);   // (previous item's last light, accumulation and the grab)
+#ifdef RT_EXP_SPAN
+        {
+            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();
+            if (t_ - span_item_begin > span_item_max) span_item_max = t_ - span_item_begin;
+        }
+#endif
         uint32_t item;
         if (!items.next(a.work, lane, item)) break;
+#ifdef RT_EXP_SPAN
+        span_item_begin = __builtin_amdgcn_s_memrealtime();
+#endif
         const int l_first = 0, l_last = L;
         const uint32_t chunk = item;
         const uint32_t base = chunk << 6;
@@ -1144,28 +1149,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         if (!load_chunk(a.q, base, count, lane, h, active)) continue;
         const f3 P = h.P;
         const SurfF own_sf = a.surf[h.own_id];
-#ifdef RT_PARK
-        // What only the Phong terms need -- view direction, weight, material -- waits in LDS (one word per value and
-        // thread, read back per light): 13 registers less across the sample loops.
-        {
-            const MatF m0 = a.mat[own_sf.mat];
-            PARK(0) = h.view.x; PARK(1) = h.view.y; PARK(2) = h.view.z;
-            PARK(3) = h.wgt.x; PARK(4) = h.wgt.y; PARK(5) = h.wgt.z;
-            PARK(6) = m0.kd[0]; PARK(7) = m0.kd[1]; PARK(8) = m0.kd[2];
-            PARK(9) = m0.ks[0]; PARK(10) = m0.ks[1]; PARK(11) = m0.ks[2];
-            PARK(12) = m0.shin;
-        }
-#define H_VIEW F3(PARK(0), PARK(1), PARK(2))
-#define H_WGT F3(PARK(3), PARK(4), PARK(5))
-#define M_SHIN PARK(12)
-#define M_KS(c) PARK(9 + (c))
-#else
         const MatF m = a.mat[own_sf.mat];
-#define H_VIEW h.view
-#define H_WGT h.wgt
-#define M_SHIN m.shin
-#define M_KS(c) m.ks[c]
-#endif
         const bool own_valid = !(h.flags & HF_NO_OWN);
         const bool own_sphere = own_valid && own_sf.type == RT_SURF_SPHERE;
         const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);  // own sphere: oc
@@ -1236,9 +1220,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 // towards the viewer) contributes exactly 0 whatever its shadow ratio: no surface
                 // is relevant for such a lane
                 const float ndl0 = dot(h.nrm, ldir);
-                const f3 view0 = H_VIEW;
+                const f3 view0 = h.view;
                 const float rv0 = 2.f * ndl0 * dot(h.nrm, view0) - dot(ldir, view0);
-                const bool lit = ndl0 > 0.f || (rv0 > 0.f || M_SHIN == 0.f);
+                const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
                 const bool any_lit = __any(lit && active);   // a light behind every hit of the chunk: nothing to classify
                 STAMP(2);
                 // The rows some lane needs go straight into the compact arrays of the sample loop (slot k, wave-uniform;
@@ -1344,10 +1328,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         own_sf.c.x * (-0.1998f * llen + 1e-5f * (llen + rho))) {
                     bool shows = ndl0 > 0.f;
                     if (!shows) {
-                        const float shin0 = M_SHIN;
-                        const f3 wgt0 = H_WGT;
+                        const float shin0 = m.shin;
+                        const f3 wgt0 = h.wgt;
                         const float sp = rv0 > 0.f ? pow_pos(rv0, shin0) : (shin0 == 0.f ? 1.f : 0.f);
-                        const float cmax = fmaxf(fmaxf(M_KS(0) * lt.col[0] * wgt0.x, M_KS(1) * lt.col[1] * wgt0.y), M_KS(2) * lt.col[2] * wgt0.z);
+                        const float cmax = fmaxf(fmaxf(m.ks[0] * lt.col[0] * wgt0.x, m.ks[1] * lt.col[1] * wgt0.y), m.ks[2] * lt.col[2] * wgt0.z);
                         shows = sp * lt.spec * lt.shadow * cmax > a.exact_min;
                     }
                     need_exact = shows;
@@ -1484,20 +1468,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
                 f3 term = F3(0.f, 0.f, 0.f);
-#ifdef RT_PARK
-                asm volatile("" ::: "memory");   // (read the parked values here, not before the sample loop)
-#endif
-                const f3 wgt1 = H_WGT;
+                const f3 wgt1 = h.wgt;
 #ifdef RT_EXP_NO_PHONG   // timing experiment
                 term = F3(ratio, ratio, ratio);
 #else
-#ifdef RT_PARK
-                MatF m;
-                m.kd[0] = PARK(6); m.kd[1] = PARK(7); m.kd[2] = PARK(8);
-                m.ks[0] = PARK(9); m.ks[1] = PARK(10); m.ks[2] = PARK(11);
-                m.shin = PARK(12);
-#endif
-                phong_add(term, h.nrm, ldir, H_VIEW, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+                phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
 #endif
                 cx += (double)(wgt1.x * term.x); cy += (double)(wgt1.y * term.y); cz += (double)(wgt1.z * term.z);
             }
@@ -1516,7 +1491,18 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 7; ++c)
-#ifdef RT_EXP_STAMPS   // timing experiment: the class counters report cycles per phase instead
+#if defined(RT_EXP_SPAN)   // timing experiment: when the waves start and finish (100 MHz clock), one frame per read-out
+            if (c == 0) {
+                const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+                atomicMax(&a.counters[CNT_WL_NONE + 0], (1ull << 44) - span_begin);   // earliest start
+                atomicMax(&a.counters[CNT_WL_NONE + 1], t_end);                          // last finish
+                atomicAdd(&a.counters[CNT_WL_NONE + 2], t_end - span_begin);             // resident time, summed
+                atomicAdd(&a.counters[CNT_WL_NONE + 3], t_end);                          // finish times, summed
+                atomicAdd(&a.counters[CNT_WL_NONE + 4], 1ull);
+                atomicAdd(&a.counters[CNT_WL_NONE + 5], span_begin);                     // start times, summed
+                atomicMax(&a.counters[CNT_WL_NONE + 6], span_item_max);                  // longest item
+            }
+#elif defined(RT_EXP_STAMPS)   // timing experiment: the class counters report cycles per phase instead
             if (c < 7) atomicAdd(&a.counters[CNT_WL_NONE + c], st_acc[c]);
 #else
             if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
