@@ -1164,7 +1164,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         unsigned long long premask = ~0ull;
         const bool prefilter = classify && L * S <= 64;
         if (prefilter) {
-            const f3 Pc = F3(__builtin_amdgcn_readfirstlane(P.x), __builtin_amdgcn_readfirstlane(P.y), __builtin_amdgcn_readfirstlane(P.z));
+            // bounding sphere of the chunk's hits: centroid (lanes without a hit hold a copy of one) and largest distance
+            f3 sp = P;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { sp.x += __shfl_xor(sp.x, o); sp.y += __shfl_xor(sp.y, o); sp.z += __shfl_xor(sp.z, o); }
+            const f3 Pc = F3(__builtin_amdgcn_readfirstlane(sp.x) * 0.015625f, __builtin_amdgcn_readfirstlane(sp.y) * 0.015625f,
+                             __builtin_amdgcn_readfirstlane(sp.z) * 0.015625f);
             const f3 dP = P - Pc;
             float rw2 = dot(dP, dP);
 #pragma unroll
