@@ -445,6 +445,7 @@ __device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, c
 __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitRec& h, const SurfF& own_sf, bool own_valid, const LightF& lt,
                                                   f3 lrel, float lc2, float linv, f3 right, f3 up, bool lit, unsigned long long reach_mask,
                                                   uint32_t key, float& ratio, uint32_t& n_gen, int& n_rows);
+__device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, f3 Lp, float light_radius, int s, f3 Pc, float Rw, bool own_uniform, int own_grp);
 
 // LINEAR: scenes without a grid (17..64 surfaces) also try the linear rows of k_shade_fast per (wave, light); the grid
 // scenes' instance leaves that code out and keeps three waves per SIMD.
@@ -480,6 +481,20 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         const double* p64 = a.q.p64 + (size_t)(base + lane) * 3;
 
         const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
+        // bounding sphere of the chunk's hits (lanes without a hit hold a copy of one): centroid and largest distance
+        f3 Pc = P;
+        float Rw = 0.f;
+        if (LINEAR && !a.grid.cell_start && a.fp.n_surfaces <= 64 && !a.no_cull) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { Pc.x += __shfl_xor(Pc.x, o); Pc.y += __shfl_xor(Pc.y, o); Pc.z += __shfl_xor(Pc.z, o); }
+            Pc = F3(__builtin_amdgcn_readfirstlane(Pc.x) * 0.015625f, __builtin_amdgcn_readfirstlane(Pc.y) * 0.015625f,
+                    __builtin_amdgcn_readfirstlane(Pc.z) * 0.015625f);
+            const f3 dP = P - Pc;
+            float rw2 = dot(dP, dP);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) rw2 = fmaxf(rw2, __shfl_xor(rw2, o));
+            Rw = __builtin_amdgcn_sqrtf(rw2) * 1.0001f;
+        }
         // Every light adds (double)(weight * term) -- the same value whichever kernel shades that (hit, light) pair --
         // and the lights are summed in float64: which pairs a wave defers depends on which hits share the wave, and
         // with FP32 sums the pixel would carry that in its last FP32 bit (a byte flips when it sits on an integer).
@@ -517,17 +532,23 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 unsigned long long reach_mask = ~0ull;
                 const int S = a.fp.n_surfaces;
                 bool linear_ok = false, linear_done = false, lit_lane = false;
-                if (!a.grid.cell_start && S <= 64 && !a.no_cull) {
+                if (LINEAR && !a.grid.cell_start && S <= 64 && !a.no_cull) {
                     reach_mask = 0ull;
-                    linear_ok = LINEAR && N < 256;
-                    const float llen = lc2 * linv;
-                    const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + llen);
-                    const float inv_lc2 = linv * linv;
+                    linear_ok = N < 256;
                     const float ndl0 = dot(nrm, ldir);
                     const float rv0 = 2.f * ndl0 * dot(nrm, view) - dot(ldir, view);
                     const bool lit = active && (ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f));
                     lit_lane = lit;
-                    for (int s = 0; s < S; ++s) {
+                    // one lane per surface tests the chunk's bounding sphere against the widened segment to the light
+                    // (chunk_may_reach; the hits' own surfaces are tested like the others: a hit lies on its surface)
+                    const bool maybe = (int)lane < S && chunk_may_reach(a, F3(lt.pos[0], lt.pos[1], lt.pos[2]), lt.radius, (int)lane, Pc, Rw, false, -1);
+                    // ... and the hits themselves test the surfaces that survive (a chunk of deeper rays' hits can be spread
+                    // over the whole scene: its bounding sphere then says little)
+                    const float llen = lc2 * linv;
+                    const float rho = lt.radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (fabsf(P.x) + fabsf(P.y) + fabsf(P.z) + llen);
+                    const float inv_lc2 = linv * linv;
+                    for (unsigned long long mm = __any(lit) ? __ballot(maybe) : 0ull; mm; mm &= mm - 1ull) {
+                        const int s = (int)__builtin_ctzll(mm);
                         const SurfF sf = uniform_load(a.surf + s);
                         bool reach;
                         if (sf.type == RT_SURF_PLANE) {
@@ -904,15 +925,18 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
 // of the corresponding segment from Pc, and the per-hit reach tests of the classification (same forms, same margins)
 // hold for all of them once Rw and the bounds of the hit-dependent allowances are added.  false: the classification of
 // that combination would find "never" in every lane, and is skipped.  Errs only towards true.
+__device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, f3 Lp, float light_radius, int s, f3 Pc, float Rw, bool own_uniform, int own_grp);
 __device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, int l, int s, f3 Pc, float Rw, bool own_uniform, int own_grp) {
     const LightF* lt = a.light + l;
+    return chunk_may_reach(a, F3(lt->pos[0], lt->pos[1], lt->pos[2]), lt->radius, s, Pc, Rw, own_uniform, own_grp);
+}
+__device__ __forceinline__ bool chunk_may_reach(const ShadeArgs& a, f3 Lp, float light_radius, int s, f3 Pc, float Rw, bool own_uniform, int own_grp) {
     const SurfF* sf = a.surf + s;
-    const f3 Lp = F3(lt->pos[0], lt->pos[1], lt->pos[2]);
     const f3 lrel = Lp - Pc;
     const float lc2 = dot(lrel, lrel);
     const float llen = __builtin_amdgcn_sqrtf(lc2);
     const float pabs = fabsf(Pc.x) + fabsf(Pc.y) + fabsf(Pc.z);
-    const float rho = lt->radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (llen + pabs + 4.f * Rw);   // >= every lane's rho
+    const float rho = light_radius * 0.70710678f * 1.0002f + 1e-6f + 4e-7f * (llen + pabs + 4.f * Rw);   // >= every lane's rho
     const int type = sf->type;
     const bool own_all = own_uniform && sf->pad == own_grp;   // every hit of the chunk lies on this surface (or a twin)
     if (type == RT_SURF_PLANE) {
@@ -1015,7 +1039,7 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
                 const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
                 const f3 q = oc + lrel * t;
                 const float reach = sf.c.w + rho;
-                if (!(dot(q, q) > reach * reach * 1.0002f)) gen = true;
+                if (!(dot(q, q) > reach * reach * 1.0002f)) gen = true;   // (a box in reach: the generic loop)
             }
         }
     }
@@ -1066,8 +1090,9 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     }
     const float ku = RT_JITTER_INV * (1.0f / (float)N) * lt.radius;
     const float koff = -0.5f * lt.radius;
-    BoxSet bx;
     float sum;
+    BoxSet bx;   // (no boxes here: a wave that reaches one takes the generic loop -- box rows were measured, and the
+                 //  registers of their sample loops cost this kernel more than the generic loop costs the few waves)
     const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
     if (a.all_opaque) {
         switch (kk) {
@@ -2014,11 +2039,7 @@ void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t aft
     const dim3 g(n_cu * 4), b(SHADE_BLOCK);
     const int S = a.fp.n_surfaces;
     if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
-#ifdef RT_EXP_NO_LINEAR_GENERAL   // timing experiment: reach mask only
-        if (false) {}
-#else
         if (!a.grid.cell_start && S <= 64 && !a.no_cull) hipLaunchKernelGGL(k_shade_general<true>, g, b, 0, s, a);
-#endif
         else hipLaunchKernelGGL(k_shade_general<false>, g, b, 0, s, a);
         if (after_main) (void)hipEventRecord(after_main, s);
     } else if (S > SMALL_MAX) {
