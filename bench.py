@@ -110,8 +110,8 @@ def main():
     ap.add_argument("--workload", default="pool_n16_4k", choices=sorted(WORKLOADS))
     ap.add_argument("--pipelines", type=int, default=0,
                     help="renderer handles (each with a stream of its own) the queued frames alternate over; "
-                         "default: 2 on one GPU, 3 when the frame is split over several (measured on one rank's share "
-                         "of the headline frame: an eighth takes 0.56 / 0.52 ms with 2 / 3, the whole frame the same)")
+                         "default: 2 on one GPU, 4 when the frame is split over several (measured on one rank's share "
+                         "of the headline frame: an eighth takes 0.53 / 0.47 / 0.43 ms with 2 / 3 / 4, the whole frame the same)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-brute-force", action="store_true",
                     help="skip the RT_FLAG_NO_CULL frames after the timed region (profiling runs: keeps per-kernel averages clean)")
@@ -135,6 +135,9 @@ def main():
                   file=sys.stderr)
         sys.exit(2)
 
+    if world > 1:
+        # HIP gives a process 4 hardware queues by default; four pipelines and the copy stream want one each
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     import raytracer_amd as R
@@ -163,7 +166,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     if args.pipelines <= 0:
-        args.pipelines = 2 if world == 1 else 3
+        args.pipelines = 2 if world == 1 else 4
     scene_name, W, H = WORKLOADS[args.workload]
     scene = R.parse_scene_file(os.path.join(ROOT, "scenes", scene_name + ".txt"))
     renderer = runtime.Renderer(local_rank)

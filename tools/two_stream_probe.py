@@ -15,7 +15,7 @@ scene = R.parse_scene_file("scenes/pool_n16.txt")
 one_lane = "--one-lane" in sys.argv
 worlds = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [1, 8]
 K = 24
-for lanes in ((1,) if one_lane else (1, 2, 3, 4)):
+for lanes in ((1,) if one_lane else tuple(int(x) for x in os.environ.get('PROBE_LANES', '1,2,3,4').split(','))):
     rs = [runtime.Renderer(0) for _ in range(lanes)]
     for r in rs:
         r.set_scene(scene)
