@@ -784,6 +784,9 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         const f2 t = (e & 1) ? pk_fma_bLcH(ur, BC[e], AA[e >> 1]) : pk_fma_bLcL(ur, BC[e], AA[e >> 1]);
         return pk_fma_bH(vr, BC[e], t);
     };
+#ifdef RT_EXP_LIVE
+    uint32_t exp_undecided = 64;
+#endif
     // decided(i0,i1,j0,j1): false = undecided for some lane, true = decided for the whole wave (and accounted for)
     auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
         const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
@@ -819,6 +822,9 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                 must_block = must_block || lo > margin;
             }
         }
+#ifdef RT_EXP_LIVE   // experiment: lanes that really need the samples of an undecided tile
+        exp_undecided = (uint32_t)__popcll(__ballot(ALL_OPAQUE ? (can_block && !must_block) : can_block));
+#endif
         if (ALL_OPAQUE) {
             if (__any(can_block && !must_block)) return false;
             open_samples += must_block ? 0u : (uint32_t)((i1 - i0) * (j1 - j0));
@@ -841,7 +847,11 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                 for (int j0 = J0; j0 < J1; j0 += T2) {
                     const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
                     if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
+#ifdef RT_EXP_LIVE
+                    n_generated += (uint32_t)((i1 - i0) * (j1 - j0)) * exp_undecided;
+#else
                     n_generated += (uint32_t)((i1 - i0) * (j1 - j0));   // (wave-uniform)
+#endif
 #ifdef RT_EXP_NO_SAMPLES   // timing experiment: everything but the sample loop
                     continue;
 #endif
@@ -1276,6 +1286,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 };
                 bool gen = false;
                 uint32_t reach_bits = 0, box_bits = 0;
+#ifdef RT_EXP_LIVE
+                uint32_t live_rows = 0;
+#endif
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
                     if (j < S && any_lit && (!prefilter || ((premask >> (l * S + j)) & 1ull))) {   // (wave-uniform)
@@ -1346,6 +1359,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                             }
                         }
                         if (__any(lin_j)) append_row(ra, rb, rc, ALL_OPAQUE ? 1.f : sf.transp);
+#ifdef RT_EXP_LIVE
+                        live_rows += lin_j ? 1u : 0u;
+#endif
                     }
                 }
                 // own sphere with c > 0 and a sample that may enter it steeply: k_shade_exact decides those samples in float64.
@@ -1385,6 +1401,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                     }
                 }
                 if (__any(own_lin)) append_row(own_a, own_b, own_c, ALL_OPAQUE ? 1.f : own_sf.b.w);
+#ifdef RT_EXP_LIVE
+                live_rows += own_lin ? 1u : 0u;
+#endif
                 uint32_t bcand = 0;
                 if (HAS_BOX) {
 #pragma unroll
@@ -1412,6 +1431,14 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         if (__ballot((reach_bits >> s) & 1u)) defer_mask |= 1u << s;
                 }
                 if (!defer) {
+#ifdef RT_EXP_LIVE   // experiment: how full are the waves that sample?  [5] lanes with a live row, [6] rows x lanes live, over sampled pairs
+                    if (k > 0) {
+                        wl_n[5] += (uint32_t)__popcll(__ballot(live_rows > 0u && active));
+                        uint32_t lr = active ? live_rows : 0u;
+                        for (int o = 32; o > 0; o >>= 1) lr += __shfl_xor(lr, o);
+                        wl_n[6] += __builtin_amdgcn_readfirstlane(lr);
+                    }
+#endif
                     wl_n[k + nb <= 4 ? k + nb : 4] += 1;
                     if (k + nb > 0) {
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
@@ -1486,7 +1513,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         }
                         ratio = sum * inv_n2;
                         STAMP(5);
+#ifdef RT_EXP_LIVE
+                        n_samples += (unsigned long long)n_gen;
+#else
                         n_samples += (unsigned long long)n_gen * n_active;
+#endif
                     }
                 }
             }
