@@ -1198,6 +1198,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
         //      one surface, a few hundredths of a scene unit across, and reach one surface per light or none.
         unsigned long long premask = ~0ull;
         const bool prefilter = classify && L * S <= 64;
+        const bool own_sphere_any = __any(own_sphere);
         if (prefilter) {
             // bounding sphere of the chunk's hits: centroid (lanes without a hit hold a copy of one) and largest distance
             f3 sp = P;
@@ -1245,7 +1246,11 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             const float lc2 = dot(lrel, lrel);
             const float linv = lc2 > 0.f ? __builtin_amdgcn_rsqf(lc2) : 0.f;
             const f3 ldir = lrel * linv;
-            if (!defer) {
+            // No surface of this light survived the chunk pre-test and no hit of the chunk lies on a sphere (whose own entry
+            // and float64 listing do not go through the pre-test): ratio = 1 without the light basis or any classification.
+            const bool nothing_to_do = prefilter && !own_sphere_any && ((premask >> (l * S)) & ((1ull << S) - 1ull)) == 0ull;
+            if (!defer && nothing_to_do) wl_n[0] += 1;
+            if (!defer && !nothing_to_do) {
                 const f3 perp = fabsf(ldir.x) > 0.1f ? F3(0.f, 1.f, 0.f) : F3(1.f, 0.f, 0.f);  // light.py:24-27
                 const f3 right = normalize(cross(ldir, perp));
                 const f3 up = normalize(cross(right, ldir));
