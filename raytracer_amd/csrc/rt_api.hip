@@ -590,9 +590,26 @@ int build_grid(rt_handle* h, const std::vector<SurfD>& sd, int S) {
         for (int z = c0[2]; z <= c1[2]; ++z) for (int y = c0[1]; y <= c1[1]; ++y) for (int x = c0[0]; x <= c1[0]; ++x)
             items[fill[((size_t)z * g.n[1] + y) * g.n[0] + x]++] = (uint32_t)s;
     }
-    const size_t words = start.size() + items.size() + std::max<size_t>(global_items.size(), 1);
+    // bounding sphere of every list entry, in FP32 (radius grown by what the FP32 centre may be off)
+    std::vector<float> bounds(items.size() * 4, 0.f);
+    for (size_t k = 0; k < (size_t)start[cells]; ++k) {
+        const SurfD& a = sd[items[k]];
+        double c[3], r;
+        if (a.type == RT_SURF_SPHERE) { for (int q = 0; q < 3; ++q) c[q] = a.d[q]; r = std::fabs(a.d[3]); }
+        else {
+            double dd2 = 0;
+            for (int q = 0; q < 3; ++q) { c[q] = 0.5 * (a.d[q] + a.d[3 + q]); const double e = 0.5 * (a.d[3 + q] - a.d[q]); dd2 += e * e; }
+            r = std::sqrt(dd2);
+        }
+        const double off = 2e-7 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]));
+        for (int q = 0; q < 3; ++q) bounds[k * 4 + q] = (float)c[q];
+        bounds[k * 4 + 3] = (float)((r + off) * (1.0 + 1e-6) + 1e-9) * 1.000001f;
+    }
+    const size_t words = bounds.size() + start.size() + items.size() + std::max<size_t>(global_items.size(), 1);
     HIP_TRY(h, hipMalloc(&h->d_grid_mem, words * sizeof(uint32_t)));
     uint32_t* p = h->d_grid_mem;
+    HIP_TRY(h, hipMemcpy(p, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice));
+    g.item_bounds = (const float4*)p; p += bounds.size();   // (first: the allocation is 16-byte aligned)
     HIP_TRY(h, hipMemcpy(p, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     g.cell_start = p; p += start.size();
     HIP_TRY(h, hipMemcpy(p, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

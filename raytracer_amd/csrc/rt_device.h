@@ -51,6 +51,9 @@ struct SceneGrid {
     const uint32_t* cell_start;
     const uint32_t* items;
     const uint32_t* global_items;
+    // one bounding sphere per entry of `items` (centre xyz, radius; FP32, the radius grown by the rounding of the
+    // centre): a ray that stays clear of it cannot meet the surface, which the walks test before they load the surface
+    const float4* item_bounds;
 };
 
 struct MatF {

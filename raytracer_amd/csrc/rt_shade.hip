@@ -362,10 +362,21 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
     }
     uint32_t p0 = 0, p1 = 0;  // item range of the previously visited cell
     const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
+    float t_enter = (float)t0;
     for (int it = 0; it < max_steps; ++it) {
         const uint32_t c = (uint32_t)((idx[2] * g.n[1] + idx[1]) * g.n[0] + idx[0]);
         const uint32_t k0 = g.cell_start[c], k1 = g.cell_start[c + 1];
+        // FP32 pre-test per candidate: the ray against the entry's bounding sphere, from a local origin at the cell's
+        // entry; a sure miss spares the load of the 64-byte surface record and its test
+        const f3 ol = F3(fmaf(w.x, t_enter, P.x), fmaf(w.y, t_enter, P.y), fmaf(w.z, t_enter, P.z));
+        const float eps_cell = 3e-7f * (fabsf(ol.x) + fabsf(ol.y) + fabsf(ol.z) + t_enter) + 1e-7f;
         for (uint32_t k = k0; k < k1; ++k) {
+            const float4 bnd = g.item_bounds[k];
+            const f3 cc = F3(bnd.x, bnd.y, bnd.z) - ol;
+            const float bb = dot(cc, w);
+            const f3 qq = cc - w * bb;
+            const float rm = bnd.w + eps_cell + 2e-6f * (fabsf(cc.x) + fabsf(cc.y) + fabsf(cc.z));
+            if (dot(qq, qq) > rm * rm * 1.0001f) continue;   // (NaN: not skipped)
             const uint32_t j = g.items[k];
             bool seen = false;
             for (uint32_t q = p0; q < p1; ++q) seen = seen || g.items[q] == j;
@@ -378,6 +389,7 @@ __device__ __forceinline__ float shadow_factor(const ShadeArgs& a, f3 P, f3 w, f
         p0 = k0; p1 = k1;
         const int ax = t_max[0] <= t_max[1] ? (t_max[0] <= t_max[2] ? 0 : 2) : (t_max[1] <= t_max[2] ? 1 : 2);
         if (t_max[ax] > t1) return f;   // the segment ends (or leaves the grid) inside this cell
+        t_enter = (float)t_max[ax];
         idx[ax] += step[ax];
         if (idx[ax] < 0 || idx[ax] >= g.n[ax]) return f;
         t_max[ax] += t_delta[ax];
