@@ -115,6 +115,7 @@ struct rt_handle {
     float exact_min = 1e-4f;         // RT_EXACT_MIN: see ShadeArgs::exact_min
     size_t exact_list = 0;           // RT_EXACT_LIST: initial length of the float64 pair list (test hook; 0 = two per pixel)
     int grid_override = -1;          // RT_GRID: -1 automatic (more than kGridMinSurfaces surfaces), 0 never, 1 always
+    double grid_density = 4.0;       // RT_GRID_DENSITY: cells per bounded surface (measurement hook)
     // run-to-completion tail of the ray tree (k_trace_tail)
     bool both_children = false;      // some material spawns a reflection and a transparency child
     int tail_override = -1;          // RT_TAIL_FROM: -1 automatic, 0 never, d >= 1 from depth d on
@@ -557,7 +558,7 @@ int build_grid(rt_handle* h, const std::vector<SurfD>& sd, int S) {
     if (!(max_ext > 0)) max_ext = 1.0;
     const double grow = 1e-6 * max_ext + 1e-9;
     for (int k = 0; k < 3; ++k) { lo[k] -= 2 * grow; hi[k] += 2 * grow; ext[k] = hi[k] - lo[k]; }
-    const double target = std::min(4.0 * (double)bounded.size(), 2097152.0);
+    const double target = std::min(h->grid_density * (double)bounded.size(), 2097152.0);
     const double edge = std::cbrt(ext[0] * ext[1] * ext[2] / target);
     SceneGrid g{};
     size_t cells = 1;
@@ -639,6 +640,7 @@ int rt_create(int device, rt_handle** out) {
     // test / measurement hook: 0 = one launch per level, d >= 1 = run-to-completion kernel from depth d on (default: from the camera rays)
     if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
     if (const char* e = std::getenv("RT_GRID")) h->grid_override = std::atoi(e);  // test hook: force the grid on / off
+    if (const char* e = std::getenv("RT_GRID_DENSITY")) { const double v = std::atof(e); if (v >= 0.125 && v <= 64.0) h->grid_density = v; }
     if (const char* e = std::getenv("RT_EXACT_MIN")) h->exact_min = (float)std::atof(e);
     if (const char* e = std::getenv("RT_EXACT_LIST")) h->exact_list = (size_t)std::max(1ll, std::atoll(e));
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
