@@ -1357,7 +1357,21 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         } else {
                             if (!lit) {
                             } else if (own) {
-                                if (dot(lrel, h.nrm) - rho < 0.f) gen = true;  // some sample may enter the box
+                                if (dot(lrel, h.nrm) - rho < 0.f) {   // some sample may enter the box
+                                    // An inward sample ray leaves the box again -- later than EPSILON when the hit keeps clear
+                                    // of its face's edges, and before it reaches the light when every sample lies outside the
+                                    // box.  Then "blocked" is "inward", sv.n < 0: a row of the plane kind.
+                                    const f3 lcb = F3(lt.pos[0], lt.pos[1], lt.pos[2]) - F3(sf.c.x, sf.c.y, sf.c.z);
+                                    const float keep = sf.c.w + rho;
+                                    float edge_d = INFINITY;
+                                    if (fabsf(h.nrm.x) < 0.5f) edge_d = fminf(edge_d, fminf(P.x - sf.a.x, sf.b.x - P.x));
+                                    if (fabsf(h.nrm.y) < 0.5f) edge_d = fminf(edge_d, fminf(P.y - sf.a.y, sf.b.y - P.y));
+                                    if (fabsf(h.nrm.z) < 0.5f) edge_d = fminf(edge_d, fminf(P.z - sf.a.z, sf.b.z - P.z));
+                                    if (dot(lcb, lcb) > keep * keep * 1.0002f && edge_d > 1e-5f + 16.f * pfuzz_hit) {
+                                        ra = -dot(lrel, h.nrm) * PLANE_SCALE; rb = -dot(right, h.nrm) * PLANE_SCALE; rc = -dot(up, h.nrm) * PLANE_SCALE;
+                                        lin_j = true;
+                                    } else gen = true;
+                                }
                             } else {
                                 const f3 oc = P - F3(sf.c.x, sf.c.y, sf.c.z);  // bounding sphere
                                 const float t = fminf(fmaxf(-dot(oc, lrel) * inv_lc2, 0.f), 1.f);
