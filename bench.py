@@ -183,24 +183,36 @@ def main():
         if rehearse:
             print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
-    def timed(d, first_seed):
+    def timed(d, first_seed, retry=True):
         """K queued frames between two barriers; returns (seconds, summed stats of this rank)."""
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):
             d.enqueue(seed=first_seed + i)
+        overflow, st = 0.0, None
         try:
             st = d.finish()
         except runtime.RtError as e:
             if e.code != -5:
                 raise
+            overflow = 1.0
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:    # every rank has to take the same branch below: the retry contains collectives
+            flag = torch.tensor([overflow], dtype=torch.float64, device="cpu" if rehearse else "cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            overflow = float(flag[0])
+        if overflow:
             # a queued frame outgrew the ray / shade queues (they cannot grow while frames are in flight): size them
-            # with one synchronous frame per pipeline, which grows them, and time the K frames again
+            # with one synchronous frame per pipeline, which grows them, and time the K frames again -- once
+            if not retry:
+                if rank == 0:
+                    print("bench.py: queued frames still outgrow the queues after resizing them", file=sys.stderr)
+                sys.exit(3)
             for k in range(len(d.lanes)):
                 d.render(seed=first_seed, pipeline=k)
-            return timed(d, first_seed)
-        barrier()
-        return time.perf_counter() - t0, st
+            return timed(d, first_seed, retry=False)
+        return dt, st
 
     note("renderer ready")
     isolated = None   # kernel times of a frame rendered alone (warm-up frames run one at a time on one stream)
@@ -217,10 +229,16 @@ def main():
     wave_light = list(st["wave_light"])
     ms_shade, ms_main, flop_shade, ms_trace, ms_resolve = st["ms_shade"], st["ms_shade_main"], st["flop_shade"], st["ms_trace"], st["ms_resolve"]
     samples = st["shadow_samples"]
+    delivery = dr.delivery_report()
+    # the frame that reached the host last is compared with a synchronous render of the same seed through the plain
+    # entry point (rt_render: one stream, the runtime's own copy): every channel of every pixel within 1 LSB
     host_ok = None
     if rank == 0:
+        import numpy as np
         hf = dr.host_frame()
-        host_ok = bool(hf is not None and hf.shape == (H, W, 3) and int(hf.max()) > 0)
+        _, want, _ = renderer.render_rows(W, H, seed=1000 + args.steps - 1, want_f32=False, flags=flags)
+        host_ok = bool(hf is not None and hf.shape == want.shape and
+                       int(np.abs(hf.astype(np.int16) - want.astype(np.int16)).max()) <= 1 and int(want.max()) > 0)
 
     # ---- the same K frames left on the device (no copy to the host): reported beside the headline ------------
     dt_dev = None
@@ -275,6 +293,8 @@ def main():
             desc += " (pool geometry, 16x16 soft-shadow grid, max_recursions 10)"
         out = {
             "metric": "Mrays/s (primary+shadow+secondary) at 3840x2160 pool.txt; frame time ms",
+            "metric_note": "rays are REFERENCE-EQUIVALENT rays (what the reference casts for this frame, config.rays_definition); "
+                           "value_generated_samples_only counts only the shadow samples the kernels really generated",
             "value": rays_total / dt / 1e6,
             "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -293,6 +313,8 @@ def main():
                        "partition": f"row stripes x{world}, uint8 gather to rank 0",
                        "delivery": "uint8 frame in pinned host memory on rank 0, copy on its own stream inside the timed region",
                        "host_frame_checked": host_ok,
+                       "host_frame_check": "last delivered frame against a synchronous rt_render of the same seed: every channel within 1 LSB",
+                       "delivery_overlap": delivery,
                        "pipelines": args.pipelines,
                        "geometry_chain": "f64", "shadows_and_shading": "f32"},
             "device_resident": None if dt_dev is None else {

@@ -190,13 +190,29 @@ int rt_render_device_noalloc(rt_handle* h, const rt_render_params* p, void* dev_
  * has to be rendered again with rt_render_device, which resizes) and returns the SUMS of
  * the frames' statistics.  The selection must fit one row band (at most 3840x2160 pixels);
  * all frames between two waits must use the same stream; the outputs of frame k may be
- * consumed by later work on that stream without waiting.  Up to 8 frames are kept in
- * flight (the 9th enqueue waits for the oldest).  Every other call on the handle first
- * waits for the enqueued frames.  No counterpart in the reference (its render() is
+ * consumed by later work on that stream without waiting.  Finished frames are collected
+ * on the way (a query, not a wait), so a caller may queue long sequences: an enqueue waits
+ * for the oldest frame only with 1024 frames in flight.  Every other call on the handle
+ * first waits for the enqueued frames.  No counterpart in the reference (its render() is
  * synchronous by nature).                                                           */
 int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
                       void* stream);
 int rt_render_wait(rt_handle* h, rt_stats* stats);
+
+/* Hands finished rows to the host: the array the caller of the reference's render() receives and converts
+ * (ray_tracer.py:436-439).  Puts ONE small kernel on `stream` (NULL = the handle's stream) that copies `rows` rows
+ * of `row_bytes` bytes from device memory `dev_src` into `host_dst`, which must be pinned, device-visible host
+ * memory (hipHostMalloc, torch pin_memory).  With `dev_src_row` (device array of `rows` int32, may be NULL) the
+ * destination row y is source row dev_src_row[y]: rank 0 of a multi-GPU job assembles the frame out of the gathered
+ * stripes on the way.  Returns at once; the rows are in host memory when `stream` has passed the kernel.
+ * `workgroups` (0 = 8) sets the footprint: 6 vector registers per lane, so its waves fit beside the persistent
+ * waves of the shading kernel, and few workgroups, because a PCIe-bound kernel needs few -- 8 move a 4K frame in
+ * 0.8 ms without slowing the next frame's kernels, 64 reach the PCIe rate (0.45 ms).  The runtime's own
+ * device-to-host copy is a blit kernel with a wave on every slot of the chip: measured on the 4K pool frame, queued
+ * frames delivered with it take 2.5-3.2 ms each depending on how the copies fall, 2.44-2.55 ms with this kernel
+ * (2.40-2.45 ms with the frames left on the device).                                                             */
+int rt_deliver_rows(rt_handle* h, void* host_dst, const void* dev_src, const int32_t* dev_src_row, int64_t rows,
+                    int64_t row_bytes, int workgroups, void* stream);
 
 /* Number of rows selected by p (size of the output in rows).                       */
 int rt_rows_selected(const rt_render_params* p);

@@ -26,6 +26,7 @@ SOURCES = [
     ("rt_trace.hip", ["-ffp-contract=off"]),
     ("rt_shade.hip", ["-ffp-contract=fast-honor-pragmas"]),  # FP32 code fuses; rt_exact.h switches it off for its float64 chain
     ("rt_api.hip", ["-ffp-contract=off"]),
+    ("rt_deliver.hip", []),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 HEADERS = [os.path.join(CSRC, "rt_device.h"), os.path.join(CSRC, "rt_exact.h"), os.path.join(HERE, "..", "include", "rt_amd.h")]

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <string>
 #include <array>
 #include <map>
@@ -42,7 +43,8 @@ inline v3 normalize(v3 v) { double n = std::sqrt(dotb(v, v)); return n == 0 ? v 
 constexpr int kRayFactor = 2;    // ray-queue slots per band pixel
 constexpr int kShadeFactor = 4;  // shade-queue slots per band pixel
 constexpr size_t kMinArenaPixels = 65536;
-constexpr int kAsyncDepth = 8;         // frames rt_render_enqueue keeps in flight
+constexpr int kAsyncFirst = 32;        // bookkeeping entries (events + pinned counters) made at the first rt_render_enqueue
+constexpr int kAsyncMax = 1024;        // frames rt_render_enqueue keeps in flight before it waits for the oldest one
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
 constexpr int kQCounts = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
@@ -127,9 +129,10 @@ struct rt_handle {
     hipEvent_t ev[7]{};              // [0..3] band stages, [4] behind the main shading launch, [5], [6] begin / end of a synchronous call
     // frames enqueued by rt_render_enqueue and not yet collected
     struct Pending { hipEvent_t ev[5]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
-    Pending ring[kAsyncDepth];
-    bool ring_ready = false;
-    int ring_head = 0, ring_count = 0;   // oldest entry, entries in flight
+    std::vector<Pending*> pending_free;  // entries ready for use
+    std::deque<Pending*> in_flight;      // oldest first
+    int async_max = kAsyncMax;           // RT_ASYNC_DEPTH (measurement hook)
+    int deliver_workgroups = 0;          // RT_DELIVER_WGS: overrides the workgroup count of rt_deliver_rows (measurement hook)
     rt_stats async_sum{};                // statistics of collected frames since the last rt_render_wait
     bool async_overflow = false;
 };
@@ -432,9 +435,9 @@ void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, floa
 
 // wait for the oldest enqueued frame and add its statistics to h->async_sum
 int collect_oldest(rt_handle* h) {
-    rt_handle::Pending& e = h->ring[h->ring_head];
-    h->ring_head = (h->ring_head + 1) % kAsyncDepth;
-    h->ring_count -= 1;
+    rt_handle::Pending& e = *h->in_flight.front();
+    h->pending_free.push_back(&e);
+    h->in_flight.pop_front();
     HIP_TRY(h, hipEventSynchronize(e.ev[3]));
     float t0 = 0, t1 = 0, t1m = 0, t2 = 0, all = 0;
     HIP_TRY(h, hipEventElapsedTime(&t0, e.ev[0], e.ev[1]));
@@ -449,10 +452,40 @@ int collect_oldest(rt_handle* h) {
 }
 
 int drain(rt_handle* h) {
-    while (h->ring_count > 0) {
+    while (!h->in_flight.empty()) {
         int rc = collect_oldest(h);
-        if (rc != RT_OK) { h->ring_count = 0; return rc; }
+        if (rc != RT_OK) {
+            for (auto* e : h->in_flight) h->pending_free.push_back(e);
+            h->in_flight.clear();
+            return rc;
+        }
     }
+    return RT_OK;
+}
+
+// An entry for the next enqueued frame.  Frames that have finished are collected on the way (a query, no wait); the
+// call waits for the oldest frame only when async_max frames are in flight, so a caller that queues a long sequence is
+// never paced by the completion of its first frames.
+int take_pending(rt_handle* h, rt_handle::Pending** out) {
+    while (!h->in_flight.empty() && hipEventQuery(h->in_flight.front()->ev[3]) == hipSuccess) {
+        int rc = collect_oldest(h);
+        if (rc != RT_OK) return rc;
+    }
+    if (h->pending_free.empty() && (int)h->in_flight.size() >= h->async_max) {
+        int rc = collect_oldest(h);
+        if (rc != RT_OK) return rc;
+    }
+    if (h->pending_free.empty()) {
+        const int n = h->in_flight.empty() ? kAsyncFirst : (int)std::min<size_t>(h->in_flight.size(), 256);
+        for (int k = 0; k < n; ++k) {
+            auto* e = new rt_handle::Pending();
+            h->pending_free.push_back(e);   // owned by the handle from here on (rt_destroy releases partly built entries too)
+            for (auto& v : e->ev) HIP_TRY(h, hipEventCreate(&v));
+            HIP_TRY(h, hipHostMalloc((void**)&e->counters, sizeof(unsigned long long) * CNT_N));
+        }
+    }
+    *out = h->pending_free.back();
+    h->pending_free.pop_back();
     return RT_OK;
 }
 
@@ -641,6 +674,8 @@ int rt_create(int device, rt_handle** out) {
     if (const char* e = std::getenv("RT_TAIL_FROM")) h->tail_override = std::atoi(e);
     if (const char* e = std::getenv("RT_GRID")) h->grid_override = std::atoi(e);  // test hook: force the grid on / off
     if (const char* e = std::getenv("RT_GRID_DENSITY")) { const double v = std::atof(e); if (v >= 0.125 && v <= 64.0) h->grid_density = v; }
+    if (const char* e = std::getenv("RT_DELIVER_WGS")) h->deliver_workgroups = std::max(1, std::min(4096, std::atoi(e)));
+    if (const char* e = std::getenv("RT_ASYNC_DEPTH")) h->async_max = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("RT_EXACT_MIN")) h->exact_min = (float)std::atof(e);
     if (const char* e = std::getenv("RT_EXACT_LIST")) h->exact_list = (size_t)std::max(1ll, std::atoll(e));
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
@@ -671,9 +706,10 @@ void rt_destroy(rt_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)drain(h);
-    for (auto& e : h->ring) {
-        for (auto& v : e.ev) if (v) (void)hipEventDestroy(v);
-        if (e.counters) (void)hipHostFree(e.counters);
+    for (auto* e : h->pending_free) {
+        for (auto& v : e->ev) if (v) (void)hipEventDestroy(v);
+        if (e->counters) (void)hipHostFree(e->counters);
+        delete e;
     }
     free_frame_buffers(h);
     for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_special, (void*)h->d_counters,
@@ -883,13 +919,6 @@ int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32
     if (rows.empty()) return RT_OK;
     const size_t pixels = rows.size() * (size_t)p->width;
     if (pixels > h->max_band_pixels) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_enqueue: the selection needs more than one row band");
-    if (!h->ring_ready) {
-        for (auto& e : h->ring) {
-            for (auto& v : e.ev) HIP_TRY(h, hipEventCreate(&v));
-            HIP_TRY(h, hipHostMalloc((void**)&e.counters, sizeof(unsigned long long) * CNT_N));
-        }
-        h->ring_ready = true;
-    }
     // anything that reallocates device memory waits for the frames in flight first
     const size_t need_px = std::max(pixels, (primary_slots((size_t)p->width, rows.size()) * 2 + kShadeFactor - 1) / kShadeFactor);
     const bool need_rays = choose_tail_depth(h, h->R > 0 ? h->R : 1) > 0;
@@ -901,15 +930,16 @@ int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32
         rc = ensure_rows(h, rows.size());
         if (rc != RT_OK) return rc;
     }
-    if (h->ring_count == kAsyncDepth) { rc = collect_oldest(h); if (rc != RT_OK) return rc; }
     rc = ensure_band_capacity(h, need_px);  // no-op unless drained above (or the first frame)
     if (rc != RT_OK) return rc;
-    rt_handle::Pending& e = h->ring[(h->ring_head + h->ring_count) % kAsyncDepth];
-    e.rows = rows.size();
-    BandResult br{};
-    rc = run_band(h, p, rows.data(), (int)rows.size(), (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, false, &br, e.ev, e.counters);
+    rt_handle::Pending* e = nullptr;
+    rc = take_pending(h, &e);
     if (rc != RT_OK) return rc;
-    h->ring_count += 1;
+    e->rows = rows.size();
+    BandResult br{};
+    rc = run_band(h, p, rows.data(), (int)rows.size(), (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, false, &br, e->ev, e->counters);
+    if (rc != RT_OK) { h->pending_free.push_back(e); return rc; }
+    h->in_flight.push_back(e);
     return RT_OK;
 }
 
@@ -923,6 +953,26 @@ int rt_render_wait(rt_handle* h, rt_stats* stats) {
     h->async_overflow = false;
     if (rc != RT_OK) return rc;
     if (overflow) return fail(h, RT_ERR_QUEUE, "an enqueued frame outgrew the ray / shade queues: render it again with rt_render_device");
+    return RT_OK;
+}
+
+int rt_deliver_rows(rt_handle* h, void* host_dst, const void* dev_src, const int32_t* dev_src_row, int64_t rows, int64_t row_bytes,
+                    int workgroups, void* stream) {
+    if (!h) return RT_ERR_INVALID;
+    if (rows < 0 || row_bytes < 0 || rows > 0x7FFFFFFFll || (rows && row_bytes && (!host_dst || !dev_src)))
+        return fail(h, RT_ERR_INVALID, "rt_deliver_rows: bad rows / row_bytes / pointers");
+    if (!rows || !row_bytes) return RT_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    void* mapped = nullptr;
+    if (hipHostGetDevicePointer(&mapped, host_dst, 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        return fail(h, RT_ERR_INVALID, "rt_deliver_rows: host_dst is not pinned, device-visible host memory (hipHostMalloc / torch pin_memory)");
+    }
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    if (workgroups < 0 || workgroups > 4096) return fail(h, RT_ERR_INVALID, "rt_deliver_rows: workgroups outside [0, 4096]");
+    const int wgs = h->deliver_workgroups ? h->deliver_workgroups : (workgroups ? workgroups : 8);
+    rt_launch_deliver(mapped, dev_src, dev_src_row, (uint32_t)rows, (size_t)row_bytes, wgs, st);
+    HIP_TRY(h, hipGetLastError());
     return RT_OK;
 }
 

@@ -232,3 +232,7 @@ struct ShadeArgs {
 void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main);
 
 void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s);
+
+// rows of uint8 pixels from device memory to (pinned, device-visible) host memory; src_row (device, may be null)
+// names the source row of every destination row (rt_deliver.hip)
+void rt_launch_deliver(void* dst, const void* src, const int32_t* src_row, uint32_t rows, size_t row_bytes, int workgroups, hipStream_t s);

@@ -14,6 +14,7 @@ is done by ``librt_amd.so`` writing straight into the tensor's memory.
 """
 from __future__ import annotations
 
+import os
 import time
 
 import numpy as np
@@ -93,10 +94,12 @@ class TileGatherer:
             self.gathered = [self.buffer[r] for r in range(self.world)]
             self.source_row = torch.as_tensor(source_rows(self.H, self.world, self.stripe_rows, self.max_rows),
                                               dtype=torch.long, device=device)
+            self.source_row32 = self.source_row.to(torch.int32)     # the same list for rt_deliver_rows
             self.frame = torch.empty((self.H, self.W, 3), dtype=torch.uint8, device=device)
 
-    def gather(self):
-        """Frame (H, W, 3) uint8 on rank 0, None elsewhere; with one rank, the tile itself."""
+    def gather(self, assemble=True):
+        """Frame (H, W, 3) uint8 on rank 0, None elsewhere; with one rank, the tile itself.  ``assemble=False`` leaves
+        the gathered tiles in ``buffer`` (rank 0 then reads them through ``source_row32``) and returns None."""
         if self.world == 1:
             return self.tile[: len(self.my_rows)]
         if self.stage_host:
@@ -106,7 +109,7 @@ class TileGatherer:
                 self.buffer.copy_(self.torch.stack(host))
         else:
             self.dist.gather(self.tile, self.gathered if self.rank == 0 else None, dst=0, group=self.group)
-        if self.rank != 0:
+        if self.rank != 0 or not assemble:
             return None
         self.torch.index_select(self.buffer.view(self.world * self.max_rows, self.W, 3), 0, self.source_row, out=self.frame)
         return self.frame
@@ -164,6 +167,7 @@ class _Pipeline:
         self.count = 0          # frames put on this pipeline
         self.host = None        # pinned host frames, one per buffer set (rank 0, to_host)
         self.copied = None      # events: the copy out of buffer set b has finished
+        self.spans = []         # (first event of a queued frame on this stream, event behind its last kernel)
 
 
 class DistributedRenderer:
@@ -174,9 +178,12 @@ class DistributedRenderer:
     work items of frame k drain (two pipelines: 10 % more frames per second on a full 4K frame, 41 % on an eighth
     of it; a third one did not help).  Frame k is complete when ``finish()`` returns.
 
-    ``to_host``: on rank 0 every queued frame is also copied into pinned host memory (``host_frame``), on a copy
-    stream of its own, behind the kernels of the following frames -- the uint8 frame the caller of the reference's
-    ``render()`` ends up with (ray_tracer.py:436-439).
+    ``to_host``: on rank 0 every queued frame is delivered into pinned host memory (``host_frame``) by the library's
+    row kernel (``rt_deliver_rows``) on a stream of its own, beside the kernels of the following frames -- the uint8
+    frame the caller of the reference's ``render()`` ends up with (ray_tracer.py:436-439).  With several ranks that
+    kernel reads the gathered tiles directly, so the frame is assembled on its way to the host and exists only there
+    (``enqueue`` / ``render`` then return None for the device frame).  ``RT_DELIVER=memcpy`` selects the runtime's
+    own copy instead (A/B measurements).
     """
 
     def __init__(self, renderer, width, height, group=None, stripe_rows=None, flags=0, pipelines=1, to_host=False):
@@ -218,6 +225,11 @@ class DistributedRenderer:
                 lane.host = [torch.empty((self.H, self.W, 3), dtype=torch.uint8).pin_memory() for _ in lane.gs]
                 lane.copied = [torch.cuda.Event() for _ in lane.gs]
         self.last_host_frame = None
+        self.copy_spans = []    # (event before, event behind) every delivery on the copy stream since the last report
+        self.use_memcpy = os.environ.get("RT_DELIVER") == "memcpy"
+        # footprint of the delivery kernel: it has to keep up with the frame rate and no more -- one GPU renders a 4K
+        # frame in ~2.5 ms (8 workgroups deliver it in 0.8 ms), eight GPUs in a fraction of that (64: the PCIe rate)
+        self.deliver_workgroups = min(64, 8 * self.world)
         self.deliver = True     # set False to leave the following frames on the device (same buffers, no host copy)
 
     def _frame(self, lane, seed, queued):
@@ -228,17 +240,42 @@ class DistributedRenderer:
         if self.copy_stream is not None and lane.count >= len(lane.gs):
             cur.wait_event(lane.copied[b])      # this buffer set is still the source of an earlier copy
         lane.count += 1
+        timing = queued and self.copy_stream is not None
+        if timing:
+            begin = torch.cuda.Event(enable_timing=True)
+            begin.record(cur)
         call = lane.r.enqueue_rows_device if queued else lane.r.render_rows_device
         stats = call(self.W, self.H, 0, g.tile.data_ptr(), stream=cur.cuda_stream, seed=seed, stripe_rows=self.stripe_rows,
                      stripe_count=self.world, stripe_index=self.rank, flags=self.flags)
-        frame = g.gather()
-        if self.copy_stream is not None and frame is not None and self.deliver:
-            done = torch.cuda.Event()
+        to_host = self.copy_stream is not None and self.deliver
+        frame = g.gather(assemble=not to_host or self.use_memcpy)
+        if timing:
+            done = torch.cuda.Event(enable_timing=True)
             done.record(cur)
+            lane.spans.append((begin, done))
+        if to_host:
+            if not timing:
+                done = torch.cuda.Event()
+                done.record(cur)
             self.copy_stream.wait_event(done)
-            with torch.cuda.stream(self.copy_stream):
-                lane.host[b][: frame.shape[0]].copy_(frame, non_blocking=True)
-                lane.copied[b].record(self.copy_stream)
+            if timing:
+                c0 = torch.cuda.Event(enable_timing=True)
+                c0.record(self.copy_stream)
+            if self.use_memcpy:
+                with torch.cuda.stream(self.copy_stream):
+                    lane.host[b][: frame.shape[0]].copy_(frame, non_blocking=True)
+            elif g.world == 1:
+                lane.r.deliver_rows(lane.host[b].data_ptr(), g.tile.data_ptr(), len(g.my_rows), self.W * 3,
+                                    workgroups=self.deliver_workgroups, stream=self.copy_stream.cuda_stream)
+            else:
+                lane.r.deliver_rows(lane.host[b].data_ptr(), g.buffer.data_ptr(), self.H, self.W * 3,
+                                    src_row_ptr=g.source_row32.data_ptr(), workgroups=self.deliver_workgroups,
+                                    stream=self.copy_stream.cuda_stream)
+            lane.copied[b].record(self.copy_stream)
+            if timing:
+                c1 = torch.cuda.Event(enable_timing=True)
+                c1.record(self.copy_stream)
+                self.copy_spans.append((c0, c1))
             self.last_host_frame = lane.host[b]
         return frame, stats
 
@@ -301,6 +338,36 @@ class DistributedRenderer:
         if error is not None:
             raise error
         return total
+
+    def delivery_report(self):
+        """Where the deliveries of the frames queued since the last call ran, from events on the streams (call after
+        ``finish()``): time the copy stream was busy per frame, and the share of that time during which a pipeline
+        stream was rendering ANOTHER frame -- 1.0 means every copy ran beside kernels, 0.0 that the GPU did nothing
+        else meanwhile.  None on ranks that deliver nothing."""
+        spans, copies = [s for lane in self.lanes for s in lane.spans], self.copy_spans
+        for lane in self.lanes:
+            lane.spans = []
+        self.copy_spans = []
+        if not copies or not spans:
+            return None
+        t0 = spans[0][0]
+        frames = sorted((t0.elapsed_time(a), t0.elapsed_time(b)) for a, b in spans)
+        busy = hidden = 0.0
+        for c0, c1 in copies:
+            a, b = t0.elapsed_time(c0), t0.elapsed_time(c1)
+            busy += b - a
+            # union of the frames' render intervals, clipped to [a, b]; a frame whose kernels end at the copy's start is
+            # the frame being copied (its interval ends where the copy begins and adds nothing)
+            cover, edge = 0.0, a
+            for fa, fb in frames:
+                lo, hi = max(fa, edge), min(fb, b)
+                if hi > lo:
+                    cover += hi - lo
+                    edge = hi
+            hidden += cover
+        n = len(copies)
+        return {"frames": n, "copy_stream_busy_ms_per_frame": busy / n, "share_of_copy_time_beside_rendering": hidden / busy if busy > 0 else None,
+                "copy": "memcpy" if self.use_memcpy else "rt_deliver_rows"}
 
     def host_frame(self):
         """Pinned host copy (numpy view) of the most recently queued frame on rank 0 (valid after ``finish()``)."""

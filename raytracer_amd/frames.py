@@ -42,7 +42,7 @@ class FrameStream:
         if depth < 2:
             raise ValueError("FrameStream needs a ring of at least 2 frames")
         if depth > 8:
-            raise ValueError("FrameStream: at most 8 frames in flight (the library's ring of enqueued frames)")
+            raise ValueError("FrameStream: at most 8 frames in flight (each holds a device and a pinned host frame)")
         self.torch = torch
         self.r = renderer
         self.W, self.H, self.depth, self.flags = int(width), int(height), int(depth), int(flags)
@@ -87,9 +87,10 @@ class FrameStream:
                                        seed=seed, flags=self.flags)
         self.rendered[slot].record(render_stream)
         self.copy_stream.wait_event(self.rendered[slot])
-        with torch.cuda.stream(self.copy_stream):
-            self.host_frames[slot].copy_(self.dev_frames[slot], non_blocking=True)
-            self.copied[slot].record(self.copy_stream)
+        # the library's row kernel, not the runtime's copy: it runs beside the next frame's kernels (rt_deliver_rows)
+        self.r.deliver_rows(self.host_frames[slot].data_ptr(), self.dev_frames[slot].data_ptr(), self.H, self.W * 3,
+                            stream=self.copy_stream.cuda_stream)
+        self.copied[slot].record(self.copy_stream)
         self.submitted += 1
         return out
 

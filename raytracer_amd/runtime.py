@@ -17,7 +17,7 @@ from . import packing
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_amd.so")
 
 EXPORTS = ("rt_create", "rt_destroy", "rt_last_error", "rt_set_scene", "rt_render", "rt_render_device",
-           "rt_render_device_noalloc", "rt_render_enqueue", "rt_render_wait", "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
+           "rt_render_device_noalloc", "rt_render_enqueue", "rt_render_wait", "rt_deliver_rows", "rt_rows_selected", "rt_debug_hits", "rt_jitter_bits")
 
 HF_CBATCH_POS, HF_CDOT_POS, HF_BOX_OUTSIDE, HF_NO_OWN = 1, 2, 4, 8
 
@@ -59,6 +59,8 @@ def load_library():
     L.rt_render_enqueue.argtypes = [vp, C.POINTER(packing.RtRenderParams), vp, vp, vp]
     L.rt_render_wait.restype = C.c_int
     L.rt_render_wait.argtypes = [vp, C.POINTER(packing.RtStats)]
+    L.rt_deliver_rows.restype = C.c_int
+    L.rt_deliver_rows.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, C.c_int, vp]
     L.rt_rows_selected.restype = C.c_int
     L.rt_rows_selected.argtypes = [C.POINTER(packing.RtRenderParams)]
     L.rt_debug_hits.restype = C.c_int
@@ -158,6 +160,13 @@ class Renderer:
         """Like ``render_rows_device`` but returns as soon as the frame is on the stream; ``wait()`` collects."""
         p = packing.render_params(width, height, row_begin, row_end, stripe_rows, stripe_count, stripe_index, seed, flags)
         self._check(self._lib.rt_render_enqueue(self._h, C.byref(p), dev_f32_ptr or None, dev_u8_ptr or None, stream or None))
+
+    def deliver_rows(self, host_ptr, dev_ptr, rows, row_bytes, *, src_row_ptr=None, workgroups=0, stream=None):
+        """Enqueue the copy of ``rows`` rows of ``row_bytes`` bytes from device memory into PINNED host memory on
+        ``stream`` (raw pointers); ``src_row_ptr``: device int32 array naming the source row of every destination row;
+        ``workgroups``: footprint of the copy kernel (0 = 8: hides beside other kernels; 64 reaches the PCIe rate)."""
+        self._check(self._lib.rt_deliver_rows(self._h, host_ptr, dev_ptr, src_row_ptr or None, int(rows), int(row_bytes),
+                                              int(workgroups), stream or None))
 
     def wait(self):
         """Block until every enqueued frame is done; returns the summed stats dict (raises if one overflowed)."""

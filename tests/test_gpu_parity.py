@@ -442,6 +442,33 @@ def test_frame_stream_delivers_every_frame_to_the_host_in_order(renderer):
         FrameStream(renderer, w, h, depth=9)
 
 
+def test_deliver_rows_copies_and_gathers_into_pinned_memory(renderer):
+    """rt_deliver_rows: plain copy and row gather, 16-byte / 4-byte / 1-byte row widths, any workgroup count; memory
+    that is not pinned is refused (the kernel would fault on it)."""
+    import torch
+    dev = torch.device("cuda", renderer.device)
+    g = torch.Generator().manual_seed(5)
+    for rows, row_bytes in ((37, 11520), (50, 3 * 500), (9, 3 * 333), (1, 16), (2160, 3 * 3840)):
+        src = torch.randint(0, 256, (rows + 5, row_bytes), dtype=torch.uint8, generator=g).to(dev)
+        host = torch.zeros((rows, row_bytes), dtype=torch.uint8).pin_memory()
+        for wgs in (0, 1, 64):
+            host.zero_()
+            renderer.deliver_rows(host.data_ptr(), src.data_ptr(), rows, row_bytes, workgroups=wgs)
+            torch.cuda.synchronize()
+            assert torch.equal(host, src[:rows].cpu())
+        order = torch.randperm(rows + 5, generator=g)[:rows].to(torch.int32)
+        host.zero_()
+        renderer.deliver_rows(host.data_ptr(), src.data_ptr(), rows, row_bytes, src_row_ptr=order.to(dev).data_ptr(), workgroups=7)
+        torch.cuda.synchronize()
+        assert torch.equal(host, src.cpu()[order.long()])
+    pageable = torch.zeros((4, 64), dtype=torch.uint8)
+    with pytest.raises(runtime.RtError):
+        renderer.deliver_rows(pageable.data_ptr(), src.data_ptr(), 4, 64)
+    with pytest.raises(runtime.RtError):
+        renderer.deliver_rows(host.data_ptr(), src.data_ptr(), 4, 64, workgroups=-1)
+    renderer.deliver_rows(0, 0, 0, 64)          # nothing to do is not an error
+
+
 def test_frame_stream_on_a_fresh_handle_with_a_deep_ray_tree(oracle, tmp_path):
     """A handle that never rendered synchronously, and a scene whose ray tree outgrows the initial queues (transparency
     scene with 9 levels): queued frames cannot grow the queues, so FrameStream sizes them with a synchronous first
