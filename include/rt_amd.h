@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 2
+#define RT_ABI_VERSION 3
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -167,8 +167,10 @@ int rt_render(rt_handle* h, const rt_render_params* p, float* host_rgb_f32, uint
 int rt_render_device(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32, void* dev_rgb_u8,
                      void* stream, rt_stats* stats);
 
-/* No counterpart in the reference.  For callers that cannot allocate device memory: code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc.  Same contract as rt_render_device (device
+/* No counterpart in the reference.  For callers that cannot allocate device memory: tight serving loops, harnesses
+ * that forbid hipMalloc, memory budgets fixed at start-up.  The call still SYNCHRONISES (it waits for `stream` and reads
+ * its counters on the host), so it must not be made on a stream that is being captured into a HIP graph: "allocates
+ * nothing" is all it promises.  Same contract as rt_render_device (device
  * output pointers, work on `stream`, returns after the stream has drained), but the ray / shade queues, the
  * accumulators and the work lists live in a static __device__ array of RT_NOALLOC_SCRATCH_BYTES that the library
  * holds on every GPU it runs on until the process ends, and the call makes no hipMalloc / hipFree (rt_create

@@ -18,13 +18,20 @@ both sides are driven by a stream keyed on *what* is being sampled instead of
     draw  = 2*(i*N+j) + axis   (axis 0 = u, 1 = v), i outer / j inner as in
             light.py:51-52
 
-One 32-bit hash serves TWO neighbouring samples of a row of the grid, one byte per
-coordinate: samples (i, 2q) and (i, 2q+1) share the hash of counter i*ceil(N/2) + q; the
-even sample takes bytes 3 (u) and 2 (v), the odd one bytes 1 (u) and 0 (v).  Every value is
-an 8-bit integer scaled by 2**-8 -- 1/256 of a grid cell, i.e. 1/4096 of the light's edge at
-N = 16 -- so it is exact in float32 and float64 alike, and so is cell index + value.  (On the
-GPU the hash is the larger part of the per-sample arithmetic; halving it and extracting
-bytes, which the hardware converts to float in one instruction, is what the layout is for.)
+One 32-bit word serves TWO neighbouring samples of a row of the grid, one byte per
+coordinate: samples (i, 2q) and (i, 2q+1) share the word of pair p = i*ceil(N/2) + q; the
+even sample takes bytes 3 (u) and 2 (v), the odd one bytes 1 (u) and 0 (v).  The word is
+
+    pair_word(p) ^ key        pair_word(p) = mix32(p * GOLDEN + PAIR_SALT)
+
+i.e. ONE table of well-mixed words indexed by the pair alone, scrambled per (pixel, node,
+light) grid by XOR with the grid's key (a digital shift).  XOR with a constant permutes the
+256 values of a byte, so every coordinate stays uniform whatever the key; two grids differ
+by the XOR of their keys, which are full mix32 outputs.  (On the GPU all lanes of a
+wavefront walk the table at the same index, so the table word comes through the scalar unit
+and a pair of samples costs one vector XOR instead of a hash per lane.)  Every value is an
+8-bit integer scaled by 2**-8 -- 1/256 of a grid cell, i.e. 1/4096 of the light's edge at
+N = 16 -- so it is exact in float32 and float64 alike, and so is cell index + value.
 """
 
 M32 = 0xFFFFFFFF
@@ -42,15 +49,12 @@ def mix32(x: int) -> int:
     return x
 
 
-def pair_hash(x: int) -> int:
-    """Hash of a pair counter: one multiply between two xor-shifts.  The keys it is added to are full mix32 outputs, so
-    one round is enough for jitter (uniform bytes, no measurable correlation between the four bytes or between
-    neighbouring pairs); on the GPU it is 5 of the ~25 instructions a pair of samples costs, the two-round mix32 was 8."""
-    x &= M32
-    x ^= x >> 16
-    x = (x * 0x7FEB352D) & M32
-    x ^= x >> 15
-    return x
+PAIR_SALT = 0x5BF03635
+
+
+def pair_word(pair: int) -> int:
+    """Entry ``pair`` of the jitter table (independent of seed, pixel, node and light)."""
+    return mix32((pair * GOLDEN + PAIR_SALT) & M32)
 
 
 def stream_key(seed: int, pixel: int, node: int, light: int) -> int:
@@ -69,7 +73,7 @@ def sample_bits(key: int, n: int, s: int):
     """The two 8-bit integers (u, v) of sample ``s = i*n+j`` of an ``n`` x ``n`` grid."""
     i, j = divmod(s, n)
     pair = i * ((n + 1) >> 1) + (j >> 1)
-    m = pair_hash((key + pair * GOLDEN) & M32)
+    m = pair_word(pair) ^ key
     if j & 1:
         return (m >> 8) & 0xFF, m & 0xFF
     return m >> 24, (m >> 16) & 0xFF

@@ -100,7 +100,7 @@ static inline double comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a
 static inline uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x;
 }
-static inline uint32_t pair_hash(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; return x; }
+static inline uint32_t pair_word(uint32_t pair) { return mix32(pair * 0x9E3779B9u + 0x5BF03635u); }
 static inline uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t node, uint32_t light) {
     uint32_t k = mix32(seed + 0x9E3779B9u);
     k = mix32(k ^ pixel);
@@ -111,7 +111,7 @@ static inline uint32_t stream_key(uint32_t seed, uint32_t pixel, uint32_t node, 
 /* sample s = i*n + j of an n x n grid: one hash per two neighbours of a row, one byte per coordinate */
 static inline void sample_bits(uint32_t key, uint32_t n, uint32_t s, uint32_t* u, uint32_t* v) {
     uint32_t i = s / n, j = s % n;
-    uint32_t m = pair_hash(key + (i * ((n + 1u) >> 1) + (j >> 1)) * 0x9E3779B9u);
+    uint32_t m = pair_word(i * ((n + 1u) >> 1) + (j >> 1)) ^ key;
     if (j & 1u) { *u = (m >> 8) & 0xFFu; *v = m & 0xFFu; }
     else { *u = m >> 24; *v = (m >> 16) & 0xFFu; }
 }

@@ -96,6 +96,7 @@ struct rt_handle {
     LightF* d_light = nullptr;
     double* d_light64 = nullptr;         // float64 position xyz + radius per light (exact own-sphere evaluation)
     uint32_t* d_special = nullptr;  // per light: surfaces its centre lies on (ShadeArgs::special); null if none
+    uint32_t* d_jitter = nullptr;   // table of jitter pair words for the scene's N x N grid (ShadeArgs::jitter_words)
     int has_box = 0, all_opaque = 1;
     double shadow_rays_per_hit = 0;  // sum over lights of 1 or N*N
     double flop_per_hit = 0;         // algorithmic FP32 flop per shaded hit
@@ -109,7 +110,13 @@ struct rt_handle {
     unsigned long long* host_counters = nullptr;  // pinned: the band's counters land here (no staging by the runtime)
     int32_t* host_rows = nullptr;    // pinned copy of the row list on the device (the upload reads it in stream order)
     size_t host_rows_cap = 0;
-    hipStream_t rows_stream = nullptr;  // stream the last upload of the row list was ordered on
+    // The row list on the device is read by every band's kernels and rewritten when the selection changes.  rows_ev (owned by
+    // the handle) is recorded behind the last kernel of every band; a band on another stream than the previous one first
+    // waits for it, so the event always stands for ALL earlier readers, and the list is rewritten only after it has fired.
+    // rows_stream_id is compared, never passed to the runtime: the caller may have destroyed that stream since.
+    hipEvent_t rows_ev = nullptr;
+    bool rows_ev_recorded = false;
+    const void* rows_stream_id = nullptr;
     void* scratch = nullptr;         // this device's copy of the static scratch array (rt_render_device_noalloc)
     // uniform grid over the bounded surfaces (large scenes)
     SceneGrid grid{};
@@ -291,18 +298,27 @@ int ensure_tail_stack(rt_handle* h, int& blocks) {
     return RT_OK;
 }
 
-// The device copy of the band's row list (FrameParams::row_y).  The upload reads a pinned host buffer in stream order,
-// so before that buffer is rewritten the stream of the previous upload is drained (the list changes rarely: another
-// selection of rows, or a frame split into bands).
+// every reader of the device row list so far has finished (see rt_handle::rows_ev)
+int wait_for_row_readers(rt_handle* h) {
+    if (!h->rows_ev_recorded) return RT_OK;
+    hipError_t e = hipEventSynchronize(h->rows_ev);
+    if (e != hipSuccess) {
+        h->rows_on_device.clear();
+        return fail(h, RT_ERR_DEVICE, std::string("hipEventSynchronize(rows_ev): ") + hipGetErrorString(e));
+    }
+    return RT_OK;
+}
+
+// The device copy of the band's row list (FrameParams::row_y).  The upload reads a pinned host buffer in stream order and
+// earlier bands' kernels -- on this or on another stream -- may still read the device copy, so both are rewritten only
+// after every earlier band has finished (the list changes rarely: another selection of rows, or a frame split into bands).
 int upload_rows(rt_handle* h, const int32_t* rows, int n_rows, hipStream_t st) {
     if (h->rows_on_device.size() == (size_t)n_rows && !std::memcmp(h->rows_on_device.data(), rows, sizeof(int32_t) * n_rows)) return RT_OK;
     if ((size_t)n_rows > h->host_rows_cap) return fail(h, RT_ERR_INVALID, "row list longer than its staging buffer");
-    if (h->rows_stream) HIP_TRY(h, hipStreamSynchronize(h->rows_stream));
-    if (h->rows_stream != st) HIP_TRY(h, hipStreamSynchronize(st));   // kernels of an earlier band may still read the device copy
+    { int rc = wait_for_row_readers(h); if (rc != RT_OK) return rc; }
     h->rows_on_device.clear();
     std::memcpy(h->host_rows, rows, sizeof(int32_t) * n_rows);
     HIP_TRY(h, hipMemcpyAsync(h->fm.d_row_y, h->host_rows, sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, st));
-    h->rows_stream = st;
     h->rows_on_device.assign(rows, rows + n_rows);
     return RT_OK;
 }
@@ -311,7 +327,7 @@ int upload_rows(rt_handle* h, const int32_t* rows, int n_rows, hipStream_t st) {
 int ensure_rows(rt_handle* h, size_t n) {
     if (n > h->host_rows_cap) {
         if (h->no_alloc) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: more rows than the row staging buffer holds");
-        if (h->rows_stream) HIP_TRY(h, hipStreamSynchronize(h->rows_stream));
+        { int rc = wait_for_row_readers(h); if (rc != RT_OK) return rc; }
         if (h->host_rows) (void)hipHostFree(h->host_rows);
         h->host_rows = nullptr; h->host_rows_cap = 0; h->rows_on_device.clear();
         HIP_TRY(h, hipHostMalloc((void**)&h->host_rows, sizeof(int32_t) * n));
@@ -319,6 +335,7 @@ int ensure_rows(rt_handle* h, size_t n) {
     }
     if (n > h->fm.row_y_cap) {
         if (h->no_alloc) return fail(h, RT_ERR_UNSUPPORTED, "rt_render_device_noalloc: more rows than the static scratch has room for");
+        { int rc = wait_for_row_readers(h); if (rc != RT_OK) return rc; }
         if (h->fm.d_row_y) (void)hipFree(h->fm.d_row_y);
         h->fm.d_row_y = nullptr; h->fm.row_y_cap = 0; h->rows_on_device.clear();
         HIP_TRY(h, hipMalloc(&h->fm.d_row_y, sizeof(int32_t) * n));
@@ -342,6 +359,8 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         if (rc != RT_OK) return rc;
     }
     h->fm.sq.base = (uint32_t)slots0;
+    if (h->rows_ev_recorded && h->rows_stream_id != (const void*)st) HIP_TRY(h, hipStreamWaitEvent(st, h->rows_ev, 0));
+    h->rows_stream_id = (const void*)st;
     { int rc = upload_rows(h, rows, n_rows, st); if (rc != RT_OK) return rc; }
     if (h->no_alloc) h->fm.accum_zero_prefix = 0;   // the scratch is shared by every handle of the device: clear what this band adds into
     HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts, st));
@@ -396,6 +415,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + 4;
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;
+        sa.jitter_words = h->d_jitter;
         sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
         sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
         rt_launch_shade(sa, h->n_cu, st, ev[4]);
@@ -403,6 +423,8 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventRecord(ev[2], st));
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->fm.d_accum, (int64_t)pixels, d_f32, d_u8, st);
     HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipEventRecord(h->rows_ev, st));   // behind the last kernel that reads the row list
+    h->rows_ev_recorded = true;
     HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : h->host_counters, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipEventRecord(ev[3], st));  // after the counters have landed: waiting for it is enough
     if (enqueue_only) {
@@ -685,6 +707,7 @@ int rt_create(int device, rt_handle** out) {
     bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts) == hipSuccess;
     if (ok) h->d_qcounts = (uint32_t*)(h->d_counters + CNT_N);
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&h->rows_ev, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->host_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->host_rows, sizeof(int32_t) * kHostRows) == hipSuccess;
     if (ok) h->host_rows_cap = kHostRows;
@@ -712,11 +735,12 @@ void rt_destroy(rt_handle* h) {
         delete e;
     }
     free_frame_buffers(h);
-    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_special, (void*)h->d_counters,
+    for (void* p : {(void*)h->d_surf, (void*)h->d_surff, (void*)h->d_mat, (void*)h->d_light, (void*)h->d_light64, (void*)h->d_special, (void*)h->d_jitter, (void*)h->d_counters,
                     (void*)h->fm.stack_mem, (void*)h->d_grid_mem, (void*)h->fm.d_row_y, (void*)h->d_out_f32, (void*)h->d_out_u8,
                     (void*)h->dbg.gpixel})
         if (p) (void)hipFree(p);
     for (auto& e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->rows_ev) (void)hipEventDestroy(h->rows_ev);
     if (h->host_counters) (void)hipHostFree(h->host_counters);
     if (h->host_rows) (void)hipHostFree(h->host_rows);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -839,7 +863,7 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     cam.sdist = d->cam_screen_dist; cam.swidth = d->cam_screen_width;
 
     for (void** p : {(void**)&h->d_surf, (void**)&h->d_surff, (void**)&h->d_mat, (void**)&h->d_light, (void**)&h->d_light64,
-                     (void**)&h->d_special}) {
+                     (void**)&h->d_special, (void**)&h->d_jitter}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
     }
@@ -854,6 +878,12 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     HIP_TRY(h, hipMemcpy(h->d_light, lights.data(), sizeof(LightF) * lights.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMalloc(&h->d_light64, sizeof(double) * light64.size()));
     HIP_TRY(h, hipMemcpy(h->d_light64, light64.data(), sizeof(double) * light64.size(), hipMemcpyHostToDevice));
+    {   // jitter table: the pair words of an N x N grid (rt_device.h), the same for every seed, pixel, node and light
+        std::vector<uint32_t> words(rt_pair_table_words((uint32_t)d->n_shadow));
+        for (size_t k = 0; k < words.size(); ++k) words[k] = rt_pair_word((uint32_t)k);
+        HIP_TRY(h, hipMalloc(&h->d_jitter, sizeof(uint32_t) * words.size()));
+        HIP_TRY(h, hipMemcpy(h->d_jitter, words.data(), sizeof(uint32_t) * words.size(), hipMemcpyHostToDevice));
+    }
     int rc = build_grid(h, sd, S);
     if (rc != RT_OK) return rc;
     // lights whose centre lies on a surface (ShadeArgs::special): L + 1 offsets, then the surfaces

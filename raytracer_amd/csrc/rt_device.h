@@ -148,8 +148,6 @@ struct FrameParams {
 __host__ __device__ inline uint32_t rt_mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16; return x;
 }
-// hash of a pair counter (the keys are full rt_mix32 outputs: one round is enough for jitter)
-__host__ __device__ inline uint32_t rt_pair_hash(uint32_t x) { x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; return x; }
 __host__ __device__ inline uint32_t rt_seed_key(uint32_t seed) { return rt_mix32(seed + 0x9E3779B9u); }
 __host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixel, uint32_t node, uint32_t light) {
     uint32_t k = rt_mix32(seed_key ^ pixel);
@@ -157,15 +155,20 @@ __host__ __device__ inline uint32_t rt_grid_key(uint32_t seed_key, uint32_t pixe
     k = rt_mix32(k ^ ((light + 1u) * 0x85EBCA6Bu));
     return k;
 }
-// Sample (i, j) of an n x n grid: one hash per two neighbours of a row -- samples (i, 2q) and (i, 2q+1) share the
-// hash of counter i*ceil(n/2) + q -- and one byte per coordinate: the even sample takes bytes 3 (u) and 2 (v), the odd
-// one bytes 1 (u) and 0 (v).  The jitter is byte / 256 of a grid cell.
+// Sample (i, j) of an n x n grid: samples (i, 2q) and (i, 2q+1) share one 32-bit word, one byte per coordinate -- the
+// even sample takes bytes 3 (u) and 2 (v), the odd one bytes 1 (u) and 0 (v); the jitter is byte / 256 of a grid cell.
+// The word is  rt_pair_word(i * ceil(n/2) + q) ^ key : a fixed table of well-mixed words indexed by the pair alone,
+// scrambled per (pixel, node, light) by XOR with the grid's key.  Every byte of the result is uniform whatever the key,
+// grids of different pixels differ by the XOR of their keys, and all lanes of a wavefront walk the table at the same
+// index: the shading kernel reads the table word through the scalar unit and spends ONE vector instruction per pair.
 #define RT_JITTER_INV 0.00390625f   // 2^-8
-__host__ __device__ inline uint32_t rt_pair_counter(uint32_t key, uint32_t n, uint32_t i, uint32_t q) {
-    return key + (i * ((n + 1u) >> 1) + q) * 0x9E3779B9u;
-}
+__host__ __device__ inline uint32_t rt_pair_stride(uint32_t n) { return (n + 1u) >> 1; }
+__host__ __device__ inline uint32_t rt_pair_word(uint32_t pair) { return rt_mix32(pair * 0x9E3779B9u + 0x5BF03635u); }
+// words of the table a scene with an n x n grid reads (rows i = 0..n, so that the row after the last may be prefetched,
+// plus one 4-word load past the end)
+__host__ __device__ inline uint32_t rt_pair_table_words(uint32_t n) { return (n + 1u) * rt_pair_stride(n) + 8u; }
 __host__ __device__ inline void rt_sample_bits(uint32_t key, uint32_t n, uint32_t i, uint32_t j, uint32_t& u, uint32_t& v) {
-    const uint32_t m = rt_pair_hash(rt_pair_counter(key, n, i, j >> 1));
+    const uint32_t m = rt_pair_word(i * rt_pair_stride(n) + (j >> 1)) ^ key;
     if (j & 1u) { u = (m >> 8) & 0xFFu; v = m & 0xFFu; }
     else { u = m >> 24; v = (m >> 16) & 0xFFu; }
 }
@@ -217,6 +220,7 @@ struct ShadeArgs {
     // with such a light is shaded by k_shade_exact, with those surfaces tested in float64 (list entries with
     // RT_PAIR_FULL set).
     const uint32_t* special;
+    const uint32_t* jitter_words;   // rt_pair_word(0 .. rt_pair_table_words(N) - 1), read at wave-uniform indices
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;

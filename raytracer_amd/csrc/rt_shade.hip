@@ -429,11 +429,7 @@ struct ItemQueues {
                         // (a plain look first: waves arriving at an empty queue do not queue up behind each other's atomics)
                         const uint32_t seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (seen < q_len) {
-#ifdef RT_EXP_BATCH           // timing experiment: larger batches take the work counters out of the picture
-                            const uint32_t batch = RT_EXP_BATCH;
-#else
                             const uint32_t batch = (seen + single_below < q_len) ? 4u : 1u;
-#endif
                             g0 = atomicAdd(ctr, batch);
                             g1 = g0 + batch;
                         }
@@ -771,20 +767,26 @@ struct Rows {
     }
 };
 
+// One instruction per maximum (the compiler's fmaxf first canonicalises operands that come out of inline assembly: two
+// extra v_max_f32 per value), and the three-operand form for two further rows at once.
+__device__ __forceinline__ float vmax2(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+__device__ __forceinline__ float vmax3_zero(float a, float b) { float d; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f2 pk_sq_minus(f2 a, f2 c) {         // a * a - c
+    f2 d; asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d;
+}
+struct JitterWords4 { uint32_t w[4]; };   // the table words of the (up to) four sample pairs of one tile row
+
 template <int K, int NB, bool ALL_OPAQUE>
-__device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, float koff, float lc2, const Rows& R,
-                                                 const BoxSet& bx, uint32_t& n_generated) {
-    // The grid is walked in tiles of T1 x T1 cells, undecided ones again in T2 x T2 sub-tiles.
-    // Every entry is affine in (ur, vr) minus len, so its range over a tile's rectangle follows
-    // from the corners; when, for every lane of the wave, either no entry can block anywhere in
-    // the tile or (opaque scenes) one entry blocks everywhere, the tile's samples are not generated
-    // at all (the jitter stream is keyed by the sample index, so skipping samples does not shift
-    // the others).  With transparent surfaces only "nothing can block" decides a tile: a blocked
-    // sample's factor depends on which entries block it.
-#ifndef RT_T2
-#define RT_T2 8
-#endif
-    constexpr int T1 = 8, T2 = RT_T2;  // equal: one level (a second, finer level was measured slower: more registers than it saves samples)
+__device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint32_t* jitter_words, float ku, float koff, float lc2,
+                                                 const Rows& R, const BoxSet& bx, uint32_t& n_generated) {
+    // The grid is walked in tiles of T x T cells.  Every entry is affine in (ur, vr) minus len, so its range over a
+    // tile's rectangle follows from the corners; when, for every lane of the wave, either no entry can block anywhere
+    // in the tile or (opaque scenes) one entry blocks everywhere, the tile's samples are not generated at all (the
+    // jitter stream is keyed by the sample index, so skipping samples does not shift the others).  With transparent
+    // surfaces only "nothing can block" decides a tile: a blocked sample's factor depends on which entries block it.
+    // (A second, finer tile level was measured slower: more registers than it saves samples.)
+    constexpr int T = 8;
     const float cell = 256.0f * ku;    // width of one grid cell in ur / vr units
     uint32_t open_samples = 0;         // opaque scenes: samples nothing blocks
     float sum = 0.f;                   // otherwise: sum of the samples' light factors
@@ -796,9 +798,6 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         const f2 t = (e & 1) ? pk_fma_bLcH(ur, BC[e], AA[e >> 1]) : pk_fma_bLcL(ur, BC[e], AA[e >> 1]);
         return pk_fma_bH(vr, BC[e], t);
     };
-#ifdef RT_EXP_LIVE
-    uint32_t exp_undecided = 64;
-#endif
     // decided(i0,i1,j0,j1): false = undecided for some lane, true = decided for the whole wave (and accounted for)
     auto tile_decided = [&](int i0, int i1, int j0, int j1) -> bool {
         const float ua = fmaf((float)i0, cell, koff), ub = fmaf((float)i1, cell, koff);
@@ -834,9 +833,6 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
                 must_block = must_block || lo > margin;
             }
         }
-#ifdef RT_EXP_LIVE   // experiment: lanes that really need the samples of an undecided tile
-        exp_undecided = (uint32_t)__popcll(__ballot(ALL_OPAQUE ? (can_block && !must_block) : can_block));
-#endif
         if (ALL_OPAQUE) {
             if (__any(can_block && !must_block)) return false;
             open_samples += must_block ? 0u : (uint32_t)((i1 - i0) * (j1 - j0));
@@ -846,96 +842,100 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, float ku, 
         }
         return true;
     };
-#ifdef RT_EXP_NO_TILES   // timing experiment: classification only
-    return (float)(N * N);
-#endif
-    for (int I0 = 0; I0 < N; I0 += T1) {
-        const int I1 = I0 + T1 < N ? I0 + T1 : N;
-        for (int J0 = 0; J0 < N; J0 += T1) {
-            const int J1 = J0 + T1 < N ? J0 + T1 : N;
-            if (tile_decided(I0, I1, J0, J1)) continue;
-            for (int i0 = I0; i0 < I1; i0 += T2) {
-                const int i1 = i0 + T2 < I1 ? i0 + T2 : I1;
-                for (int j0 = J0; j0 < J1; j0 += T2) {
-                    const int j1 = j0 + T2 < J1 ? j0 + T2 : J1;
-                    if ((I1 - I0 > T2 || J1 - J0 > T2) && tile_decided(i0, i1, j0, j1)) continue;
-#ifdef RT_EXP_LIVE
-                    n_generated += (uint32_t)((i1 - i0) * (j1 - j0)) * exp_undecided;
-#else
-                    n_generated += (uint32_t)((i1 - i0) * (j1 - j0));   // (wave-uniform)
-#endif
-#ifdef RT_EXP_NO_SAMPLES   // timing experiment: everything but the sample loop
-                    continue;
-#endif
-                    // Two neighbouring samples of a row share one hash (rt_device.h) and are evaluated together in
-                    // packed FP32 (v_pk_fma_f32: both samples' FMA in one instruction): .x = sample j, .y = sample j + 1.
-                    // A tile starts at an even column, so pairs never straddle tiles; only the last pair of a row of
-                    // an odd grid has no second sample.
-                    const f2 KU = F2(ku, 2.f * cell);    // (jitter step, two columns)
-                    const f2 vcol0 = F2(fmaf((float)j0, cell, koff), fmaf((float)(j0 + 1), cell, koff));   // left edges of columns j0, j0 + 1
-                    const bool odd_tail = ((j1 - j0) & 1) != 0;
-                    for (int i = i0; i < i1; ++i) {
-                        uint32_t ctr = rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j0 >> 1);
-                        uint32_t mask = 0;
-                        const f2 UL = F2(fmaf((float)i, cell, koff), lc2);  // (left edge of row i, |lrel|^2)
-                        f2 vcol = vcol0;
-                        float row_sum = 0.f;
-                        for (int j = j0; j < j1; j += 2) {
-                            const uint32_t mm = rt_pair_hash(ctr);
-                            ctr += 0x9E3779B9u;
-                            const f2 ub = F2(ubyte_f32<3>(mm), ubyte_f32<1>(mm));
-                            const f2 vb = F2(ubyte_f32<2>(mm), ubyte_f32<0>(mm));
-                            const f2 ur = pk_fma_bLcL(ub, KU, UL);
-                            const f2 vr = pk_fma_bL(vb, KU, vcol);
-                            vcol = pk_add_bH(vcol, KU);
-                            const f2 len2 = pk_fma(ur, ur, pk_fma_cH(vr, vr, UL));
-                            if (ALL_OPAQUE) {
-                                f2 vmax = F2(-INFINITY, -INFINITY);
-                                if (K > 0) vmax = row_pair(0, ur, vr);
+    const uint32_t stride = rt_pair_stride((uint32_t)N);
+    const f2 KU = F2(ku, 2.f * cell);    // (jitter step, two columns)
+    for (int i0 = 0; i0 < N; i0 += T) {
+        const int i1 = i0 + T < N ? i0 + T : N;
+        for (int j0 = 0; j0 < N; j0 += T) {
+            const int j1 = j0 + T < N ? j0 + T : N;
+            if (tile_decided(i0, i1, j0, j1)) continue;
+            n_generated += (uint32_t)((i1 - i0) * (j1 - j0));   // (wave-uniform)
+            // Two neighbouring samples of a row share one jitter word (rt_device.h) and are evaluated together in packed
+            // FP32 (v_pk_fma_f32: both samples' FMA in one instruction): .x = sample j, .y = sample j + 1.  A tile
+            // starts at an even column, so pairs never straddle tiles; only the last pair of a row of an odd grid has
+            // no second sample.  The words of a tile row -- up to four pairs -- are wave-uniform: one scalar load,
+            // issued a row ahead (the table has a spare row and spare words at its end), and one XOR with the lane's key
+            // per pair.
+            const int n_pairs = (j1 - j0 + 1) >> 1;
+            const bool odd_tail = ((j1 - j0) & 1) != 0;
+            const f2 vcol0 = F2(fmaf((float)j0, cell, koff), fmaf((float)(j0 + 1), cell, koff));   // left edges of columns j0, j0 + 1
+            const uint32_t* wp = jitter_words + (uint32_t)i0 * stride + ((uint32_t)j0 >> 1);
+            JitterWords4 words = uniform_load((const JitterWords4*)wp);
+            for (int i = i0; i < i1; ++i) {
+                wp += stride;
+                const JitterWords4 words_next = uniform_load((const JitterWords4*)wp);
+                uint32_t mask = 0;
+                const f2 UL = F2(fmaf((float)i, cell, koff), lc2);  // (left edge of row i, |lrel|^2)
+                f2 vcol = vcol0;
+                float row_sum = 0.f;
 #pragma unroll
-                                for (int e = 1; e < K; ++e) {
-                                    const f2 lin = row_pair(e, ur, vr);
-                                    vmax.x = __builtin_fmaxf(vmax.x, lin.x); vmax.y = __builtin_fmaxf(vmax.y, lin.y);
-                                }
-                                float res0 = fmaf(vmax.x, fabsf(vmax.x), -len2.x), res1 = fmaf(vmax.y, fabsf(vmax.y), -len2.y);
-                                if (NB > 0) {
-                                    float val[NB > 0 ? NB : 1];
-                                    box_values<NB>(bx, ur.x, vr.x, val);
-#pragma unroll
-                                    for (int b = 0; b < NB; ++b) res0 = __builtin_fmaxf(res0, val[b]);
-                                    box_values<NB>(bx, ur.y, vr.y, val);
-#pragma unroll
-                                    for (int b = 0; b < NB; ++b) res1 = __builtin_fmaxf(res1, val[b]);
-                                }
-                                // sign bit set <=> nothing blocks this sample
-                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res0), 31);
-                                mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res1), 31);
-                            } else {
-                                float f0 = 1.f, f1 = 1.f;
-#pragma unroll
-                                for (int e = 0; e < K; ++e) {
-                                    const f2 lin = row_pair(e, ur, vr);
-                                    f0 = fmaf(lin.x, fabsf(lin.x), -len2.x) >= 0.f ? f0 * tr[e] : f0;
-                                    f1 = fmaf(lin.y, fabsf(lin.y), -len2.y) >= 0.f ? f1 * tr[e] : f1;
-                                }
-                                if (NB > 0) {
-                                    float val[NB > 0 ? NB : 1];
-                                    box_values<NB>(bx, ur.x, vr.x, val);
-#pragma unroll
-                                    for (int b = 0; b < NB; ++b) f0 = val[b] >= 0.f ? f0 * bx.tr[b] : f0;
-                                    box_values<NB>(bx, ur.y, vr.y, val);
-#pragma unroll
-                                    for (int b = 0; b < NB; ++b) f1 = val[b] >= 0.f ? f1 * bx.tr[b] : f1;
-                                }
-                                row_sum += f0 + ((j + 1 < j1) ? f1 : 0.f);
-                            }
-                        }
+                for (int q = 0; q < T / 2; ++q) {
+                    if (q < n_pairs) {   // (wave-uniform)
+                        const uint32_t mm = words.w[q] ^ key;
+                        const f2 ub = F2(ubyte_f32<3>(mm), ubyte_f32<1>(mm));
+                        const f2 vb = F2(ubyte_f32<2>(mm), ubyte_f32<0>(mm));
+                        const f2 ur = pk_fma_bLcL(ub, KU, UL);
+                        const f2 vr = pk_fma_bL(vb, KU, vcol);
+                        vcol = pk_add_bH(vcol, KU);
+                        const f2 len2 = pk_fma(ur, ur, pk_fma_cH(vr, vr, UL));
                         if (ALL_OPAQUE) {
-                            if (odd_tail) mask &= ~1u;   // the bit shifted in last belongs to no sample
-                            open_samples += (uint32_t)__popc(mask);
-                        } else sum += row_sum;
+                            // any entry blocks  <=>  the largest lin reaches len: lin >= len  <=>  lin * |lin| - len^2 >= 0.
+                            // With an even number of rows the last maximum takes a zero along for free, and a value
+                            // that is not negative needs no |.|: both samples' residues in one packed instruction.
+                            f2 res = F2(-INFINITY, -INFINITY);
+                            if (K > 0) {
+                                f2 vm = row_pair(0, ur, vr);
+#pragma unroll
+                                for (int e = 1; e + 1 < K - (K % 2 == 0 ? 1 : 0); e += 2) {
+                                    const f2 l1 = row_pair(e, ur, vr), l2 = row_pair(e + 1, ur, vr);
+                                    vm.x = vmax3(vm.x, l1.x, l2.x); vm.y = vmax3(vm.y, l1.y, l2.y);
+                                }
+                                if (K % 2 == 0) {
+                                    const f2 l1 = row_pair(K - 1, ur, vr);
+                                    vm.x = vmax3_zero(vm.x, l1.x); vm.y = vmax3_zero(vm.y, l1.y);
+                                    res = pk_sq_minus(vm, len2);
+                                } else {
+                                    res.x = fmaf(vm.x, fabsf(vm.x), -len2.x); res.y = fmaf(vm.y, fabsf(vm.y), -len2.y);
+                                }
+                            }
+                            if (NB > 0) {
+                                float val[NB > 0 ? NB : 1];
+                                box_values<NB>(bx, ur.x, vr.x, val);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) res.x = __builtin_fmaxf(res.x, val[b]);
+                                box_values<NB>(bx, ur.y, vr.y, val);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) res.y = __builtin_fmaxf(res.y, val[b]);
+                            }
+                            // sign bit set <=> nothing blocks this sample
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res.x), 31);
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(res.y), 31);
+                        } else {
+                            float f0 = 1.f, f1 = 1.f;
+#pragma unroll
+                            for (int e = 0; e < K; ++e) {
+                                const f2 lin = row_pair(e, ur, vr);
+                                f0 = fmaf(lin.x, fabsf(lin.x), -len2.x) >= 0.f ? f0 * tr[e] : f0;
+                                f1 = fmaf(lin.y, fabsf(lin.y), -len2.y) >= 0.f ? f1 * tr[e] : f1;
+                            }
+                            if (NB > 0) {
+                                float val[NB > 0 ? NB : 1];
+                                box_values<NB>(bx, ur.x, vr.x, val);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) f0 = val[b] >= 0.f ? f0 * bx.tr[b] : f0;
+                                box_values<NB>(bx, ur.y, vr.y, val);
+#pragma unroll
+                                for (int b = 0; b < NB; ++b) f1 = val[b] >= 0.f ? f1 * bx.tr[b] : f1;
+                            }
+                            row_sum += f0 + ((odd_tail && q == n_pairs - 1) ? 0.f : f1);
+                        }
                     }
                 }
+                if (ALL_OPAQUE) {
+                    if (odd_tail) mask &= ~1u;   // the bit shifted in last belongs to no sample
+                    open_samples += (uint32_t)__popc(mask);
+                } else sum += row_sum;
+                words = words_next;
             }
         }
     }
@@ -1118,17 +1118,17 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
     if (a.all_opaque) {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, true>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
         }
     } else {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, false>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
         }
     }
     ratio = sum * (1.0f / (float)(N * N));
@@ -1161,33 +1161,13 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(tword >> 32)) << 32);
 #define STYPE(j) ((uint32_t)(tword >> (4 * (j))) & 0xFu)
 
-#ifdef RT_EXP_SPAN
-    const unsigned long long span_begin = __builtin_amdgcn_s_memrealtime();
-    unsigned long long span_item_max = 0, span_item_begin = span_begin;
-#endif
-#ifdef RT_EXP_STAMPS
-    unsigned long long st_acc[7] = {0, 0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
-#define STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
-#else
-#define STAMP(i)
-#endif
     uint32_t wl_n[7] = {0, 0, 0, 0, 0, 0, 0};
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
     ItemQueues items;
     items.init((count + 63u) >> 6, n_waves);
     for (;;) {
-        STAMP(0);   // (previous item's last light, accumulation and the grab)
-#ifdef RT_EXP_SPAN
-        {
-            const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();
-            if (t_ - span_item_begin > span_item_max) span_item_max = t_ - span_item_begin;
-        }
-#endif
         uint32_t item;
         if (!items.next(a.work, lane, item)) break;
-#ifdef RT_EXP_SPAN
-        span_item_begin = __builtin_amdgcn_s_memrealtime();
-#endif
         const int l_first = 0, l_last = L;
         const uint32_t chunk = item;
         const uint32_t base = chunk << 6;
@@ -1229,26 +1209,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             const bool maybe = (int)lane < L * S && chunk_may_reach(a, cl, cs, Pc, Rw, own_uniform, grp0);
             premask = __ballot(maybe);
         }
-#ifdef RT_EXP_COUNT_PREMASK // experiment: combinations that survive the pre-test, reported in the single-ray class
-        wl_n[6] += (uint32_t)__popcll(premask);
-#endif
-#ifdef RT_EXP_NO_CLASSIFY   // timing experiment: no surface is classified
-        premask = 0ull;
-#endif
-
-        STAMP(1);
         double cx = 0.0, cy = 0.0, cz = 0.0;   // lights summed in float64 (see k_shade_general)
-#ifdef RT_EXP_NO_LIGHTS     // timing experiment: load and accumulate only
-        cx = P.x; cy = P.y; cz = P.z;
-        for (int l = 0; l < 0; ++l) {
-#else
         for (int l = l_first; l < l_last; ++l) {
-#endif
             if (a.special && a.special[l] != a.special[l + 1]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
             }
-            STAMP(6);
             const LightF lt = uniform_load(a.light + l);
             bool defer = lt.point_path || !classify;
             uint32_t defer_mask = defer ? (1u << SM) - 1u : 0u;  // surfaces the generic loop has to test for this (wave, light)
@@ -1281,7 +1247,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 const float rv0 = 2.f * ndl0 * dot(h.nrm, view0) - dot(ldir, view0);
                 const bool lit = ndl0 > 0.f || (rv0 > 0.f || m.shin == 0.f);
                 const bool any_lit = __any(lit && active);   // a light behind every hit of the chunk: nothing to classify
-                STAMP(2);
                 // The rows some lane needs go straight into the compact arrays of the sample loop (slot k, wave-uniform;
                 // surfaces in ascending order, the own sphere last): a lane that does not need a row holds an inert one.
                 Rows R;
@@ -1303,9 +1268,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                 };
                 bool gen = false;
                 uint32_t reach_bits = 0, box_bits = 0;
-#ifdef RT_EXP_LIVE
-                uint32_t live_rows = 0;
-#endif
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
                     if (j < S && any_lit && (!prefilter || ((premask >> (l * S + j)) & 1ull))) {   // (wave-uniform)
@@ -1390,9 +1352,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                             }
                         }
                         if (__any(lin_j)) append_row(ra, rb, rc, ALL_OPAQUE ? 1.f : sf.transp);
-#ifdef RT_EXP_LIVE
-                        live_rows += lin_j ? 1u : 0u;
-#endif
                     }
                 }
                 // own sphere with c > 0 and a sample that may enter it steeply: k_shade_exact decides those samples in float64.
@@ -1413,14 +1372,9 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                     }
                     need_exact = shows;
                 }
-                STAMP(3);
                 float own_a = -INFINITY, own_b = 0.f, own_c = 0.f;
                 bool own_lin = false;
-#ifdef RT_EXP_NO_OWN   // timing experiment: no own-sphere entry
-                if (false) {
-#else
                 if (own_sph_blocks && lit) {
-#endif
                     const float r = own_sf.c.x;
                     const float dl = dot(lrel, ov);
                     if (dl - rho * r * 1.0002f < 0.f) {  // some sample may enter the own sphere
@@ -1432,9 +1386,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                     }
                 }
                 if (__any(own_lin)) append_row(own_a, own_b, own_c, ALL_OPAQUE ? 1.f : own_sf.b.w);
-#ifdef RT_EXP_LIVE
-                live_rows += own_lin ? 1u : 0u;
-#endif
                 uint32_t bcand = 0;
                 if (HAS_BOX) {
 #pragma unroll
@@ -1462,14 +1413,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         if (__ballot((reach_bits >> s) & 1u)) defer_mask |= 1u << s;
                 }
                 if (!defer) {
-#ifdef RT_EXP_LIVE   // experiment: how full are the waves that sample?  [5] lanes with a live row, [6] rows x lanes live, over sampled pairs
-                    if (k > 0) {
-                        wl_n[5] += (uint32_t)__popcll(__ballot(live_rows > 0u && active));
-                        uint32_t lr = active ? live_rows : 0u;
-                        for (int o = 32; o > 0; o >>= 1) lr += __shfl_xor(lr, o);
-                        wl_n[6] += __builtin_amdgcn_readfirstlane(lr);
-                    }
-#endif
                     wl_n[k + nb <= 4 ? k + nb : 4] += 1;
                     if (k + nb > 0) {
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
@@ -1509,46 +1452,40 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                                 }
                             }
                         }
-                        STAMP(4);
                         float sum;
                         uint32_t n_gen = 0;
                         if (!HAS_BOX || nb == 0) {
                             switch (k) {
-                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                             }
                         } else {
                             // boxes: linear rows rounded up to 0 / 2 / 4 / 8 (spare rows are inert), boxes to 1 or NBMAX
                             const int kk = k == 0 ? 0 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
                             if (nb == 1) {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             } else {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
-                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             }
                         }
                         ratio = sum * inv_n2;
-                        STAMP(5);
-#ifdef RT_EXP_LIVE
-                        n_samples += (unsigned long long)n_gen;
-#else
                         n_samples += (unsigned long long)n_gen * n_active;
-#endif
                     }
                 }
             }
@@ -1561,20 +1498,12 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
             } else {
                 f3 term = F3(0.f, 0.f, 0.f);
                 const f3 wgt1 = h.wgt;
-#ifdef RT_EXP_NO_PHONG   // timing experiment
-                term = F3(ratio, ratio, ratio);
-#else
                 phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
-#endif
                 cx += (double)(wgt1.x * term.x); cy += (double)(wgt1.y * term.y); cz += (double)(wgt1.z * term.z);
             }
         }
         if (active && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
             const uint32_t lp = h.lpix;
-#ifdef RT_EXP_NO_ATOMICS    // timing experiment: plain stores (wrong image)
-            a.accum[(size_t)0 * a.npix + lp] = cx; a.accum[(size_t)1 * a.npix + lp] = cy; a.accum[(size_t)2 * a.npix + lp] = cz;
-            continue;
-#endif
             unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], cx);
             unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], cy);
             unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], cz);
@@ -1583,22 +1512,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 7; ++c)
-#if defined(RT_EXP_SPAN)   // timing experiment: when the waves start and finish (100 MHz clock), one frame per read-out
-            if (c == 0) {
-                const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
-                atomicMax(&a.counters[CNT_WL_NONE + 0], (1ull << 44) - span_begin);   // earliest start
-                atomicMax(&a.counters[CNT_WL_NONE + 1], t_end);                          // last finish
-                atomicAdd(&a.counters[CNT_WL_NONE + 2], t_end - span_begin);             // resident time, summed
-                atomicAdd(&a.counters[CNT_WL_NONE + 3], t_end);                          // finish times, summed
-                atomicAdd(&a.counters[CNT_WL_NONE + 4], 1ull);
-                atomicAdd(&a.counters[CNT_WL_NONE + 5], span_begin);                     // start times, summed
-                atomicMax(&a.counters[CNT_WL_NONE + 6], span_item_max);                  // longest item
-            }
-#elif defined(RT_EXP_STAMPS)   // timing experiment: the class counters report cycles per phase instead
-            if (c < 7) atomicAdd(&a.counters[CNT_WL_NONE + c], st_acc[c]);
-#else
             if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
-#endif
         if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
     }
 }
@@ -1753,7 +1667,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
                 const float cu = ((float)i * invN - 0.5f) * lt.radius;
                 uint32_t mm = 0;
                 for (int j = 0; j < N; ++j) {
-                    if (!(j & 1)) mm = rt_pair_hash(rt_pair_counter(key, (uint32_t)N, (uint32_t)i, (uint32_t)j >> 1));   // one hash per two samples
+                    if (!(j & 1)) mm = rt_pair_word((uint32_t)i * rt_pair_stride((uint32_t)N) + ((uint32_t)j >> 1)) ^ key;   // one word per two samples
                     const uint32_t ub = (j & 1) ? (mm >> 8) & 0xFFu : mm >> 24;
                     const uint32_t vb = (j & 1) ? mm & 0xFFu : (mm >> 16) & 0xFFu;
                     const float cv = ((float)j * invN - 0.5f) * lt.radius;

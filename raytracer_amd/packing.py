@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-RT_ABI_VERSION = 2
+RT_ABI_VERSION = 3
 RT_SURF_SPHERE, RT_SURF_PLANE, RT_SURF_BOX, RT_SURF_PLANE_RAW = 0, 1, 2, 3
 RT_MAT_STRIDE, RT_LIGHT_STRIDE = 11, 9
 

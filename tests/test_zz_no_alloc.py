@@ -95,3 +95,67 @@ def test_noalloc_rejects_what_does_not_fit():
         assert st["primary_rays"] == 512 * 512
     finally:
         r.close()
+
+
+def _free_bytes(torch):
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]
+
+
+@pytest.mark.parametrize("name", ["pool", "transparency_v7"])   # v7: a material reflects AND transmits, so the ray tree's
+def test_noalloc_moves_no_device_memory(name):                  # stack of parked children comes out of the scratch too
+    """What the entry point exists for: the device's free memory is the same before and after the call (a hipMalloc or
+    hipFree anywhere below it -- a queue that grows, a row list, an event pool -- would move it)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(scene(name))
+        u8 = torch.zeros((200, 320, 3), dtype=torch.uint8, device=dev)
+        f32 = torch.zeros((200, 320, 3), dtype=torch.float32, device=dev)
+        want = torch.zeros_like(u8)
+        r.render_rows_device(320, 200, 0, want.data_ptr(), seed=9)            # the handle is warm: arena, row list, events
+        r.render_rows_device_noalloc(320, 200, f32.data_ptr(), u8.data_ptr(), seed=8)
+        free0 = _free_bytes(torch)
+        for k, (w, h) in enumerate([(320, 200), (96, 54), (320, 200)]):
+            r.render_rows_device_noalloc(w, h, f32.data_ptr(), u8.data_ptr(), seed=9)
+            assert _free_bytes(torch) == free0, (k, w, h)
+        assert np.array_equal(u8.cpu().numpy(), want.cpu().numpy())
+        # a fresh handle that never allocated an arena: the first call may not allocate either
+        r2 = runtime.Renderer(0)
+        try:
+            r2.set_scene(scene(name))
+            free1 = _free_bytes(torch)
+            r2.render_rows_device_noalloc(320, 200, f32.data_ptr(), u8.data_ptr(), seed=9)
+            assert _free_bytes(torch) == free1
+            assert np.array_equal(u8.cpu().numpy(), want.cpu().numpy())
+        finally:
+            r2.close()
+    finally:
+        r.close()
+
+
+def test_noalloc_reports_a_ray_tree_that_outgrows_the_scratch_instead_of_growing(tmp_path):
+    """A deep tree of reflecting and transmitting hits needs more shade-queue slots than the scratch holds for the
+    frame: the call fails with RT_ERR_QUEUE, allocates nothing, and the allocating entry point renders the frame."""
+    import torch
+    import raytracer_amd as R
+    from helpers import SCENES, write_scene
+    import os
+    lines = open(os.path.join(SCENES, "transparency_v7.txt")).read().splitlines()
+    deep = [("set " + " ".join(ln.split()[1:5]) + " 14") if ln.split()[:1] == ["set"] else ln for ln in lines]
+    sc = R.parse_scene_file(write_scene(tmp_path, "\n".join(deep) + "\n"))
+    dev = torch.device("cuda", 0)
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(sc)
+        u8 = torch.zeros((256, 480, 3), dtype=torch.uint8, device=dev)
+        free0 = _free_bytes(torch)
+        with pytest.raises(runtime.RtError) as e:
+            r.render_rows_device_noalloc(480, 256, 0, u8.data_ptr(), seed=2)
+        assert e.value.code == -5, str(e.value)                   # RT_ERR_QUEUE
+        assert _free_bytes(torch) == free0
+        st = r.render_rows_device(480, 256, 0, u8.data_ptr(), seed=2)
+        assert st["shaded_points"] > 4 * 480 * 256                # more hits than the scratch layout has slots for
+    finally:
+        r.close()
