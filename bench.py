@@ -117,6 +117,8 @@ def main():
                     help="skip the RT_FLAG_NO_CULL frames after the timed region (profiling runs: keeps per-kernel averages clean)")
     ap.add_argument("--no-device-resident", action="store_true",
                     help="skip the second timed loop that leaves the frames on the device (profiling runs)")
+    ap.add_argument("--no-pool-4k", action="store_true",
+                    help="skip the extra leg on scenes/pool.txt itself (N = 5) at 3840x2160 after the timed region")
     ap.add_argument("--no-cull", action="store_true",
                     help="brute force: every shadow ray against every surface (RT_FLAG_NO_CULL), for A/B numbers")
     args = ap.parse_args()
@@ -247,6 +249,26 @@ def main():
         dt_dev, _ = timed(dr, 3000)
         dr.deliver = True
 
+    # the scene file the metric names, as it is (pool.txt: N = 5), at the same resolution and delivered the same way:
+    # reported as an extra key beside the headline (whose workload is the N = 16 configuration of the same geometry)
+    pool_4k = None
+    if world == 1 and args.workload == "pool_n16_4k" and not args.no_pool_4k and not args.no_cull:
+        r5 = runtime.Renderer(local_rank)
+        r5.set_scene(R.parse_scene_file(os.path.join(ROOT, "scenes", "pool.txt")))
+        d5 = DistributedRenderer(r5, W, H, pipelines=args.pipelines, to_host=True)
+        for i in range(max(args.warmup, 1)):
+            d5.render(seed=i)
+        d5.prepare()
+        dt5, st5 = timed(d5, 5000)
+        gen5 = st5["total_rays"] - st5["shadow_rays"] + st5["shadow_samples"]
+        pool_4k = {"workload": "scenes/pool.txt at 3840x2160 (N = 5, max_recursions 10): the scene file the metric names, as it is",
+                   "ms_per_step": dt5 / max(args.steps, 1) * 1e3, "value": st5["total_rays"] / dt5 / 1e6, "unit": "Mrays/s",
+                   "rays_per_frame": st5["total_rays"] / max(args.steps, 1),
+                   "value_generated_samples_only": gen5 / dt5 / 1e6, "steps": args.steps,
+                   "delivery": "uint8 frame in pinned host memory, as the headline"}
+        del d5
+        r5.close()
+
     # the same frame with RT_FLAG_NO_CULL (every shadow ray against every surface): what the straightforward
     # kernel reaches of the vector peak; outside the timed region, rank 0 of a single-GPU run only
     brute = None
@@ -321,6 +343,7 @@ def main():
                 "ms_per_step": dt_dev / steps * 1e3, "value": rays_total / dt_dev / 1e6, "unit": "Mrays/s",
                 "note": "the same K frames with the uint8 frame left on rank 0's device (no copy to the host)"},
             "value_generated_samples_only": (rays_total - shadow_total + samples_total) / dt / 1e6,
+            "pool_4k": pool_4k,
             "wave_light_classes_rank0": dict(zip(["none", "k1", "k2", "k3", "k4", "generic", "point", "float64_pairs"], wave_light)),
             "kernel_ms_per_frame_rank0": {"trace": ms_trace / steps, "shade": ms_shade / steps, "shade_main_kernel": timed_ms,
                                           "resolve": ms_resolve / steps,

@@ -141,7 +141,9 @@ def concurrent_streams(torch, device, n, candidates=12):
     """
     kept = []
     with torch.cuda.device(device):
-        can_probe = hasattr(torch.cuda, "_sleep")   # the spin kernel of torch; without it the first n streams are taken
+        # the spin kernel of torch; without it -- or with RT_STREAM_PROBE=0, which keeps those launches out of a kernel
+        # profile -- the first n streams are taken
+        can_probe = hasattr(torch.cuda, "_sleep") and os.environ.get("RT_STREAM_PROBE") != "0"
         for _ in range(candidates):
             if len(kept) == n:
                 break

@@ -10,10 +10,11 @@ WL=${2:-pool_n16_4k}
 OUT=gpurun_out/prof_${TAG}_${WL}
 mkdir -p $OUT
 export TMPDIR=/tmp
+export RT_STREAM_PROBE=0   # no spin kernels of the stream probe in the kernel statistics
 # the default bench alternates its frames over two streams (kernels of consecutive frames overlap, so their
 # durations include shared time); the counter passes and a second trace use one stream, where a launch runs alone
-BENCH2="python3 bench.py --workload $WL --no-cpu-baseline --no-brute-force"
-BENCH="python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-brute-force --no-device-resident --pipelines 1"
+BENCH2="python3 bench.py --workload $WL --no-cpu-baseline --no-brute-force --no-pool-4k"
+BENCH="python3 bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-brute-force --no-pool-4k --no-device-resident --pipelines 1"
 T="timeout -s KILL 240"
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH2 > $OUT/trace.log 2>&1 || exit 1
 $T rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_isolated -- $BENCH > $OUT/trace_isolated.log 2>&1 || exit 1
