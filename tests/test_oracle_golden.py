@@ -115,3 +115,17 @@ def test_camera_basis_known_answer(oracle):
     f, r, u = b
     assert abs(np.dot(f, r)) < 1e-15 and abs(np.dot(f, u)) < 1e-15 and abs(np.dot(r, u)) < 1e-15
     np.testing.assert_allclose(np.cross(r, f), u, atol=1e-15)
+
+
+def test_reference_cpu_baseline_fixture_is_consistent():
+    """tests/golden/ref_cpu_baseline.json (oracle/time_reference.py: the unmodified reference timed in the build
+    container): every run's ray count is the sum of its counters and its rate follows from rays and seconds."""
+    d = golden_json("ref_cpu_baseline.json")
+    assert len(d["runs"]) == 5
+    for name, run in d["runs"].items():
+        for leg, secs in (("one_process", "seconds"), ("processes", "seconds_slowest_worker")):
+            r = run[leg]
+            c = r["counters"]
+            assert r["rays"] == c["primary"] + c["secondary"] + c["shadow"], (name, leg)
+            assert abs(r["krays_per_s"] - r["rays"] / r[secs] / 1e3) <= 0.02 * r["krays_per_s"] + 0.01, (name, leg)
+            assert c["primary"] > 0 and r[secs] > 1.0
