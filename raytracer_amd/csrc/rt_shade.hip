@@ -777,7 +777,11 @@ __device__ __forceinline__ f2 pk_sq_minus(f2 a, f2 c) {         // a * a - c
 }
 struct JitterWords4 { uint32_t w[4]; };   // the table words of the (up to) four sample pairs of one tile row
 
-template <int K, int NB, bool ALL_OPAQUE>
+// TABLE: the pair words come from the table in memory through the scalar unit (k_shade_fast: three waves per SIMD hide
+// the load, and a pair costs one vector instruction); otherwise they are computed on the scalar unit (the any-size
+// kernel runs two waves per SIMD, where waiting for the load costs more than the nine scalar instructions: a
+// 40-surface scene at 1080p, N = 8, 1.44 against 1.15 ms).
+template <int K, int NB, bool ALL_OPAQUE, bool TABLE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint32_t* jitter_words, float ku, float koff, float lc2,
                                                  const Rows& R, const BoxSet& bx, uint32_t& n_generated) {
     // The grid is walked in tiles of T x T cells.  Every entry is affine in (ur, vr) minus len, so its range over a
@@ -860,10 +864,11 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
             const bool odd_tail = ((j1 - j0) & 1) != 0;
             const f2 vcol0 = F2(fmaf((float)j0, cell, koff), fmaf((float)(j0 + 1), cell, koff));   // left edges of columns j0, j0 + 1
             const uint32_t* wp = jitter_words + (uint32_t)i0 * stride + ((uint32_t)j0 >> 1);
-            JitterWords4 words = uniform_load((const JitterWords4*)wp);
+            JitterWords4 words{}, words_next{};
+            if (TABLE) words = uniform_load((const JitterWords4*)wp);
             for (int i = i0; i < i1; ++i) {
                 wp += stride;
-                const JitterWords4 words_next = uniform_load((const JitterWords4*)wp);
+                if (TABLE) words_next = uniform_load((const JitterWords4*)wp);
                 uint32_t mask = 0;
                 const f2 UL = F2(fmaf((float)i, cell, koff), lc2);  // (left edge of row i, |lrel|^2)
                 f2 vcol = vcol0;
@@ -871,7 +876,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
 #pragma unroll
                 for (int q = 0; q < T / 2; ++q) {
                     if (q < n_pairs) {   // (wave-uniform)
-                        const uint32_t mm = words.w[q] ^ key;
+                        const uint32_t mm = (TABLE ? words.w[q] : rt_pair_word((uint32_t)i * stride + ((uint32_t)j0 >> 1) + (uint32_t)q)) ^ key;
                         const f2 ub = F2(ubyte_f32<3>(mm), ubyte_f32<1>(mm));
                         const f2 vb = F2(ubyte_f32<2>(mm), ubyte_f32<0>(mm));
                         const f2 ur = pk_fma_bLcL(ub, KU, UL);
@@ -935,7 +940,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
                     if (odd_tail) mask &= ~1u;   // the bit shifted in last belongs to no sample
                     open_samples += (uint32_t)__popc(mask);
                 } else sum += row_sum;
-                words = words_next;
+                if (TABLE) words = words_next;
             }
         }
     }
@@ -1118,17 +1123,17 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
     if (a.all_opaque) {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
         }
     } else {
         switch (kk) {
-            case 1: sum = compact_samples<1, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            case 2: sum = compact_samples<2, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            case 4: sum = compact_samples<4, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            default: sum = compact_samples<8, 0, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 1: sum = compact_samples<1, 0, false, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 2: sum = compact_samples<2, 0, false, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            case 4: sum = compact_samples<4, 0, false, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+            default: sum = compact_samples<8, 0, false, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
         }
     }
     ratio = sum * (1.0f / (float)(N * N));
@@ -1456,31 +1461,31 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         uint32_t n_gen = 0;
                         if (!HAS_BOX || nb == 0) {
                             switch (k) {
-                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                default: sum = compact_samples<8, 0, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 1: sum = compact_samples<1, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 2: sum = compact_samples<2, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 3: sum = compact_samples<3, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 4: sum = compact_samples<4, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 5: sum = compact_samples<5, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 6: sum = compact_samples<6, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                case 7: sum = compact_samples<7, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                default: sum = compact_samples<8, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                             }
                         } else {
                             // boxes: linear rows rounded up to 0 / 2 / 4 / 8 (spare rows are inert), boxes to 1 or NBMAX
                             const int kk = k == 0 ? 0 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));
                             if (nb == 1) {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    default: sum = compact_samples<8, 1, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, 1, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, 1, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, 1, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, 1, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             } else {
                                 switch (kk) {
-                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 0: sum = compact_samples<0, NBMAX, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 2: sum = compact_samples<2, NBMAX, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    case 4: sum = compact_samples<4, NBMAX, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
+                                    default: sum = compact_samples<8, NBMAX, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                                 }
                             }
                         }
