@@ -138,8 +138,6 @@ typedef struct rt_stats {
                                  holds a hit: shadow_rays above is the reference's count (N*N per hit and light),
                                  this is what is left of it after whole (wavefront, light) pairs and whole sample
                                  tiles were decided without sampling                                               */
-    double ms_shade_samples;  /* of ms_shade_main: the sampling kernel, when classification and sampling run as two
-                                 launches (scenes of up to 8 surfaces without boxes); 0 when one fused kernel does both */
 } rt_stats;
 
 typedef struct rt_handle rt_handle;

@@ -46,8 +46,7 @@ constexpr size_t kMinArenaPixels = 65536;
 constexpr int kAsyncFirst = 32;        // bookkeeping entries (events + pinned counters) made at the first rt_render_enqueue
 constexpr int kAsyncMax = 1024;        // frames rt_render_enqueue keeps in flight before it waits for the oldest one
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
-constexpr int kQCounts = 64 + 2 * (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [45..48] lists of k_shade_exact and the record arena, [64..] work counters of k_shade_fast, then those of k_shade_samples
-constexpr size_t kPairBytesPerPixel = 512;  // sample-record arena per band pixel (the headline frame uses 211; a frame that needs more is rendered fused)
+constexpr int kQCounts = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 constexpr size_t kHostRows = 16384;    // rows of the pinned row-list staging buffer made at rt_create (grows on demand)
 
@@ -75,12 +74,6 @@ struct FrameMem {
     int32_t* d_row_y = nullptr;
     size_t row_y_cap = 0;
     void* arena = nullptr;           // one allocation behind all queue arrays
-    // classification and sampling as two kernels (ShadeArgs::pair_hdr): headers per (chunk, light) and the record arena;
-    // a separate allocation, absent when the frame memory is the static scratch (the fused kernel runs then)
-    uint2* d_pair_hdr = nullptr;
-    float* d_pair_data = nullptr;
-    size_t pair_hdr_entries = 0;
-    uint32_t pair_slab_units = 0, pair_slabs = 0;
     RayQueue stack{};                // run-to-completion ray tree: parked children, [level][thread]
     void* stack_mem = nullptr;
     size_t stack_slots = 0;
@@ -128,9 +121,6 @@ struct rt_handle {
     // uniform grid over the bounded surfaces (large scenes)
     SceneGrid grid{};
     uint32_t* d_grid_mem = nullptr;
-    int split = 1;                   // RT_SPLIT=0: always the fused shading kernel (A/B measurements)
-    bool split_failed = false;       // a frame outgrew the record arena: fused until the next scene
-    bool last_band_split = false;    // the band enqueued last ran the split kernels (its event [7] is recorded)
     float exact_min = 1e-4f;         // RT_EXACT_MIN: see ShadeArgs::exact_min
     size_t exact_list = 0;           // RT_EXACT_LIST: initial length of the float64 pair list (test hook; 0 = two per pixel)
     int grid_override = -1;          // RT_GRID: -1 automatic (more than kGridMinSurfaces surfaces), 0 never, 1 always
@@ -143,9 +133,9 @@ struct rt_handle {
     float* d_out_f32 = nullptr;
     uint8_t* d_out_u8 = nullptr;
     size_t out_cap = 0;              // values
-    hipEvent_t ev[8]{};              // [0..3] band stages, [4] behind the main shading launch(es), [5], [6] begin / end of a synchronous call, [7] between the classifying and the sampling kernel
+    hipEvent_t ev[7]{};              // [0..3] band stages, [4] behind the main shading launch, [5], [6] begin / end of a synchronous call
     // frames enqueued by rt_render_enqueue and not yet collected
-    struct Pending { hipEvent_t ev[8]{}; unsigned long long* counters = nullptr; size_t rows = 0; bool split = false; };   // (events indexed as rt_handle::ev; [5], [6] unused)
+    struct Pending { hipEvent_t ev[5]{}; unsigned long long* counters = nullptr; size_t rows = 0; };
     std::vector<Pending*> pending_free;  // entries ready for use
     std::deque<Pending*> in_flight;      // oldest first
     int async_max = kAsyncMax;           // RT_ASYNC_DEPTH (measurement hook)
@@ -170,9 +160,6 @@ int fail(rt_handle* h, int code, const std::string& msg) {
 
 void free_frame_buffers(rt_handle* h) {
     if (h->fm.arena) (void)hipFree(h->fm.arena);
-    if (h->fm.d_pair_hdr) (void)hipFree(h->fm.d_pair_hdr);
-    if (h->fm.d_pair_data) (void)hipFree(h->fm.d_pair_data);
-    h->fm.d_pair_hdr = nullptr; h->fm.d_pair_data = nullptr; h->fm.pair_hdr_entries = 0; h->fm.pair_slabs = 0;
     h->fm.arena = nullptr;
     h->fm.band_capacity = 0;
     h->fm.arena_lights = 0;
@@ -258,26 +245,6 @@ int ensure_band_capacity(rt_handle* h, size_t pixels) {
     if (e != hipSuccess) return fail(h, RT_ERR_OOM, "hipMalloc of " + std::to_string(b.bytes) + " bytes for frame queues failed");
     h->fm.arena = base;
     carve_band(h, base, b, pixels, lights, need_rays);
-    // Sample records of the split shading kernels: a header per (chunk, light) and chunk, and an arena that waves carve in
-    // slabs (one atomic per slab).  Sized for kPairBytesPerPixel plus one slab per wave that can be resident; without it
-    // (allocation refused) the fused kernel runs.
-    if (h->split) {
-        const size_t chunks = b.scap / 64 + 1;
-        const size_t waves = (size_t)h->n_cu * 16;
-        const size_t data_units = pixels * kPairBytesPerPixel / 16;
-        const size_t slab_units = std::min<size_t>(16384, std::max<size_t>(1024, data_units / (waves * 8)));
-        const size_t slabs = data_units / slab_units + waves + 1;
-        if (slabs * slab_units < 0xFFFFFFFFull &&
-            hipMalloc(&h->fm.d_pair_hdr, chunks * (size_t)(lights + 1) * sizeof(uint2)) == hipSuccess &&
-            hipMalloc(&h->fm.d_pair_data, slabs * slab_units * 16) == hipSuccess) {
-            h->fm.pair_hdr_entries = chunks * (size_t)(lights + 1);
-            h->fm.pair_slab_units = (uint32_t)slab_units; h->fm.pair_slabs = (uint32_t)slabs;
-        } else {
-            (void)hipGetLastError();
-            if (h->fm.d_pair_hdr) (void)hipFree(h->fm.d_pair_hdr);
-            h->fm.d_pair_hdr = nullptr; h->fm.d_pair_data = nullptr;
-        }
-    }
     return RT_OK;
 }
 
@@ -298,7 +265,7 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
         if ((y / p->stripe_rows) % p->stripe_count == p->stripe_index) rows.push_back(y);
 }
 
-struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_shade_main, ms_shade_samples, ms_resolve; };
+struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_shade_main, ms_resolve; };
 
 void point_tail_stack(rt_handle* h, void* mem, size_t slots) {
     char* p = (char*)mem;
@@ -436,7 +403,6 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         rt_launch_trace(ta, std::max(blocks, 1), st);
     }
     HIP_TRY(h, hipEventRecord(ev[1], st));
-    bool split_launch = false;
     if (!debug) {
         ShadeArgs sa{};
         sa.fp = fp; sa.surf = h->d_surff; sa.mat = h->d_mat; sa.light = h->d_light; sa.q = h->fm.sq; sa.grid = h->grid;
@@ -450,19 +416,9 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;
         sa.jitter_words = h->d_jitter;
-        const bool split = h->fm.d_pair_hdr && !h->split_failed && h->S <= 8 && !h->has_box && !sa.no_cull && sa.variant == SHADE_AUTO &&
-                           h->N < 256 && (size_t)(h->fm.sq.capacity / 64 + 1) * (size_t)(h->L + 1) <= h->fm.pair_hdr_entries;
-        if (split) {
-            sa.pair_hdr = h->fm.d_pair_hdr; sa.pair_data = h->fm.d_pair_data;
-            sa.pair_alloc = h->d_qcounts + 48;
-            sa.pair_slab_units = h->fm.pair_slab_units; sa.pair_slabs = h->fm.pair_slabs;
-            sa.work5 = h->d_qcounts + 64 + RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE;
-        }
-        split_launch = split;
-        h->last_band_split = split;
         sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
         sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
-        rt_launch_shade(sa, h->n_cu, st, ev[4], ev[7]);
+        rt_launch_shade(sa, h->n_cu, st, ev[4]);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
     if (!debug && (d_f32 || d_u8)) rt_launch_resolve(h->fm.d_accum, (int64_t)pixels, d_f32, d_u8, st);
@@ -481,17 +437,15 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, ev[1], ev[2]));
     res->ms_shade_main = 0.f;
     if (!debug) HIP_TRY(h, hipEventElapsedTime(&res->ms_shade_main, ev[1], ev[4]));
-    res->ms_shade_samples = 0.f;
-    if (split_launch) HIP_TRY(h, hipEventElapsedTime(&res->ms_shade_samples, ev[7], ev[4]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_resolve, ev[2], ev[3]));
     if (!debug && (d_f32 || d_u8)) h->fm.accum_zero_prefix = zero_before;
     return RT_OK;
 }
 
-void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, float ms_trace, float ms_shade, float ms_shade_main, float ms_shade_samples, float ms_resolve, size_t rows) {
+void add_band_stats(rt_handle* h, rt_stats& s, const unsigned long long* c, float ms_trace, float ms_shade, float ms_shade_main, float ms_resolve, size_t rows) {
     s.primary_rays += c[CNT_PRIMARY]; s.secondary_rays += c[CNT_SECONDARY];
     s.depth_cut += c[CNT_DEPTH_CUT]; s.shaded_points += c[CNT_SHADED];
-    s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_shade_main += ms_shade_main; s.ms_shade_samples += ms_shade_samples; s.ms_resolve += ms_resolve;
+    s.ms_trace += ms_trace; s.ms_shade += ms_shade; s.ms_shade_main += ms_shade_main; s.ms_resolve += ms_resolve;
     s.shadow_samples += c[CNT_SAMPLES];
     for (int k = 0; k < 7; ++k) s.wave_light[k] += c[CNT_WL_NONE + k];
     s.wave_light[7] += c[CNT_EXACT];
@@ -507,16 +461,14 @@ int collect_oldest(rt_handle* h) {
     h->pending_free.push_back(&e);
     h->in_flight.pop_front();
     HIP_TRY(h, hipEventSynchronize(e.ev[3]));
-    float t0 = 0, t1 = 0, t1m = 0, t1s = 0, t2 = 0, all = 0;
+    float t0 = 0, t1 = 0, t1m = 0, t2 = 0, all = 0;
     HIP_TRY(h, hipEventElapsedTime(&t0, e.ev[0], e.ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&t1, e.ev[1], e.ev[2]));
     HIP_TRY(h, hipEventElapsedTime(&t1m, e.ev[1], e.ev[4]));
-    if (e.split) HIP_TRY(h, hipEventElapsedTime(&t1s, e.ev[7], e.ev[4]));
     HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
     if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->fm.exact_capacity) h->async_overflow = true;
-    if (e.counters[CNT_OVERFLOW_PAIRS]) { h->async_overflow = true; h->split_failed = true; }   // (rendering it again runs the fused kernel)
-    add_band_stats(h, h->async_sum, e.counters, t0, t1, t1m, t1s, t2, e.rows);
+    add_band_stats(h, h->async_sum, e.counters, t0, t1, t1m, t2, e.rows);
     h->async_sum.ms_total += all;
     return RT_OK;
 }
@@ -582,10 +534,6 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
         rc = run_band(h, p, rows.data() + r0, (int)n, d_f32 ? d_f32 + r0 * W * 3 : nullptr,
                       d_u8 ? d_u8 + r0 * W * 3 : nullptr, st, false, &br);
         if (rc != RT_OK) return rc;
-        if (br.c[CNT_OVERFLOW_PAIRS]) {   // the sample records outgrew their arena: this scene is shaded by the fused kernel from here on
-            h->split_failed = true;
-            continue;
-        }
         if (br.c[CNT_EXACT] > h->fm.exact_capacity && !br.c[CNT_OVERFLOW_RAY] && !br.c[CNT_OVERFLOW_SHADE]) {
             // more (hit, light) pairs needed their own sphere in float64 than the list holds (a camera inside a glass
             // ball): the counter says how many; rebuild the arena with a list of that size and render the band again
@@ -621,7 +569,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
             band_rows = std::max<size_t>(1, n / 2);  // retry this band with fewer rows
             continue;
         }
-        add_band_stats(h, s, br.c, br.ms_trace, br.ms_shade, br.ms_shade_main, br.ms_shade_samples, br.ms_resolve, 0);
+        add_band_stats(h, s, br.c, br.ms_trace, br.ms_shade, br.ms_shade_main, br.ms_resolve, 0);
         r0 += n;
     }
     HIP_TRY(h, hipEventRecord(e_end, st));
@@ -750,7 +698,6 @@ int rt_create(int device, rt_handle** out) {
     if (const char* e = std::getenv("RT_GRID_DENSITY")) { const double v = std::atof(e); if (v >= 0.125 && v <= 64.0) h->grid_density = v; }
     if (const char* e = std::getenv("RT_DELIVER_WGS")) h->deliver_workgroups = std::max(1, std::min(4096, std::atoi(e)));
     if (const char* e = std::getenv("RT_ASYNC_DEPTH")) h->async_max = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("RT_SPLIT")) h->split = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_EXACT_MIN")) h->exact_min = (float)std::atof(e);
     if (const char* e = std::getenv("RT_EXACT_LIST")) h->exact_list = (size_t)std::max(1ll, std::atoll(e));
     if (const char* e = std::getenv("RT_MAX_BAND_PIXELS")) {  // test hook: force row bands on small frames
@@ -986,7 +933,6 @@ int rt_set_scene(rt_handle* h, const rt_scene_desc* d) {
     // algorithmic FP32 flop per shaded hit: per shadow ray the surface tests + 26 for building the
     // ray; per (hit, light) 30 for the sampling basis + 52 for the Phong terms; 12 for the blend
     h->flop_per_hit = rays_per_hit * (test_flops + 26.0) + L * 82.0 + 12.0;
-    h->split_failed = false;
     h->has_scene = true;
     return RT_OK;
 }
@@ -1023,7 +969,6 @@ int rt_render_enqueue(rt_handle* h, const rt_render_params* p, void* dev_rgb_f32
     BandResult br{};
     rc = run_band(h, p, rows.data(), (int)rows.size(), (float*)dev_rgb_f32, (uint8_t*)dev_rgb_u8, st, false, &br, e->ev, e->counters);
     if (rc != RT_OK) { h->pending_free.push_back(e); return rc; }
-    e->split = h->last_band_split;
     h->in_flight.push_back(e);
     return RT_OK;
 }

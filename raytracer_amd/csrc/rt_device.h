@@ -130,7 +130,6 @@ enum { CNT_PRIMARY = 0, CNT_SECONDARY, CNT_DEPTH_CUT, CNT_SHADED, CNT_OVERFLOW_R
        CNT_WL_NONE, CNT_WL_K1, CNT_WL_K2, CNT_WL_K3, CNT_WL_K4, CNT_WL_GENERIC, CNT_WL_POINT,
        CNT_EXACT,  // (hit, light) pairs evaluated by k_shade_exact
        CNT_SAMPLES,  // shadow-ray samples generated and tested by the shading kernels (lanes holding a hit x samples)
-       CNT_OVERFLOW_PAIRS,  // sample records that found no room in the record arena (ShadeArgs::pair_data)
        CNT_N };
 
 struct FrameParams {
@@ -222,17 +221,6 @@ struct ShadeArgs {
     // RT_PAIR_FULL set).
     const uint32_t* special;
     const uint32_t* jitter_words;   // rt_pair_word(0 .. rt_pair_table_words(N) - 1), read at wave-uniform indices
-    // Classification and sampling as two kernels (null pair_hdr: one fused kernel).  The classifying kernel leaves, for every
-    // (64-hit chunk, light) whose shadow ratio needs samples, a record for the sampling kernel: the rows of the compact
-    // sample loop and what the light adds per unit of ratio.  pair_hdr[chunk * (L + 1) + l] = (record offset in 16-byte
-    // units, number of rows; 0 rows: nothing to sample); entry l = L is the chunk's own block (pixel indices and the sums of
-    // everything that does not depend on samples; .y = number of records of the chunk).  Records are carved out of
-    // pair_data in slabs of pair_slab_units that a wave takes with one atomic on pair_alloc.
-    uint2* pair_hdr;
-    float* pair_data;
-    uint32_t* pair_alloc;
-    uint32_t pair_slab_units, pair_slabs;
-    uint32_t* work5;                // work counters of the sampling kernel (RT_WORK_QUEUES, RT_WORK_QUEUE_STRIDE words apart)
     const SurfF* surf;
     const MatF* mat;
     const LightF* light;
@@ -245,12 +233,7 @@ struct ShadeArgs {
     unsigned long long* counters;
 };
 // after_main (may be null) is recorded behind the first, dominant launch
-// after_classify (may be null) is recorded between the classifying and the sampling kernel when they are two launches
-void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main, hipEvent_t after_classify = nullptr);
-// sample records: fields of 64 lanes x 4 bytes (16 units of 16 bytes)
-#define RT_PAIR_FIELD_UNITS 16u
-#define RT_PAIR_MAX_FIELDS 37u      // 5 per pair + 4 per row (A, B, C, transparency) x 8 rows
-#define RT_PAIR_CHUNK_FIELDS 7u     // pixel index + three float64 sums
+void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main);
 
 void rt_launch_resolve(double* accum, int64_t n_pixels, float* out_f32, uint8_t* out_u8, hipStream_t s);
 

@@ -449,9 +449,7 @@ struct ItemQueues {
     }
 };
 
-struct PhongPair { f3 base, slope; };
-__device__ __forceinline__ PhongPair phong_split(f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, f3 wgt);
-__device__ __forceinline__ double phong_term(float base, float slope, float ratio);
+__device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio);
 __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitRec& h, const SurfF& own_sf, bool own_valid, const LightF& lt,
                                                   f3 lrel, float lc2, float linv, f3 right, f3 up, bool lit, unsigned long long reach_mask,
                                                   uint32_t key, float& ratio, uint32_t& n_gen, int& n_rows);
@@ -632,8 +630,9 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
                 if (reach_mask) n_samples += (unsigned long long)(N * N) * n_active;
             }
             // ---- intensity (ray_tracer.py:105) and Phong terms (:157-170)
-            const PhongPair ph = phong_split(nrm, ldir, view, m, lt, hr.wgt);
-            cx += phong_term(ph.base.x, ph.slope.x, ratio); cy += phong_term(ph.base.y, ph.slope.y, ratio); cz += phong_term(ph.base.z, ph.slope.z, ratio);
+            f3 term = F3(0.f, 0.f, 0.f);
+            phong_add(term, nrm, ldir, view, m, lt, ratio);
+            cx += (double)(hr.wgt.x * term.x); cy += (double)(hr.wgt.y * term.y); cz += (double)(hr.wgt.z * term.z);
         }
         if (active) {
             const uint32_t lp = hr.lpix;
@@ -693,30 +692,21 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
 #define NBMAX 3                // boxes it can test beside them
 #define PLANE_SCALE 1152921504606846976.0f  // 2^60
 
-// Intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light.  The light adds
-//   weight * (diffuse + specular) * ((1 - shadow_intensity) + shadow_intensity * ratio)
-// to the pixel, which is affine in the shadow ratio: every kernel evaluates it as  base + slope * ratio  with
-//   base = weight * (V * (1 - shadow_intensity)),  slope = weight * (V * shadow_intensity),  V = diffuse + specular
-// in FP32 and adds (double)base + (double)(slope * ratio) -- the same two values whichever kernel shades the
-// (hit, light) pair and whether or not the ratio is known where V is (the kernel that classifies a pair may leave its
-// samples to another one, which then only needs the slope).
-__device__ __forceinline__ PhongPair phong_split(f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, f3 wgt) {
-    const float ndl = fmaxf(0.f, dot(nrm, ldir));
-    const float k2 = 2.f * dot(ldir, nrm);
-    const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
-    const float rv = dot(rdir, view);
-    const float sp = rv > 0.f ? pow_pos(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
-    const float spi = sp * lt.spec;
-    const f3 V = F3(m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi, m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi,
-                    m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi);
-    const float lit = 1.0f - lt.shadow;
-    PhongPair p;
-    p.base = F3(wgt.x * (V.x * lit), wgt.y * (V.y * lit), wgt.z * (V.z * lit));
-    p.slope = F3(wgt.x * (V.x * lt.shadow), wgt.y * (V.y * lt.shadow), wgt.z * (V.z * lt.shadow));
-    return p;
+// intensity (ray_tracer.py:105) and Phong terms (:157-170) of one light
+__device__ __forceinline__ void phong_add(f3& color, f3 nrm, f3 ldir, f3 view, const MatF& m, const LightF& lt, float ratio) {
+    const float inten = (1.0f - lt.shadow) + lt.shadow * ratio;
+    if (inten != 0.f) {
+        const float ndl = fmaxf(0.f, dot(nrm, ldir));
+        const float k2 = 2.f * dot(ldir, nrm);
+        const f3 rdir = nrm * k2 - ldir;  // reflect(-L, n)
+        const float rv = dot(rdir, view);
+        const float sp = rv > 0.f ? pow_pos(rv, m.shin) : (m.shin == 0.f ? 1.f : 0.f);
+        const float spi = sp * lt.spec;
+        color.x += (m.kd[0] * lt.col[0] * ndl + m.ks[0] * lt.col[0] * spi) * inten;
+        color.y += (m.kd[1] * lt.col[1] * ndl + m.ks[1] * lt.col[1] * spi) * inten;
+        color.z += (m.kd[2] * lt.col[2] * ndl + m.ks[2] * lt.col[2] * spi) * inten;
+    }
 }
-// the light's addition to one channel for a known shadow ratio
-__device__ __forceinline__ double phong_term(float base, float slope, float ratio) { return (double)base + (double)(slope * ratio); }
 
 // N x N jittered samples of one light against K compacted linear tests.  Entry e blocks the
 // sample iff  lin_e = A + ur*B + vr*C >= len  (tangent cone of a sphere; a plane crossing
@@ -1150,35 +1140,7 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     return true;
 }
 
-// Room for the sample records of one wave: slabs of the record arena, taken with one atomic each (a record per atomic
-// would queue the whole launch up behind one counter word), and filled front to back.
-struct SlabCursor {
-    uint32_t pos = 0, end = 0;   // 16-byte units, wave-uniform
-    // offset of `units` units, or 0xFFFFFFFF when the arena is exhausted (counted: the host then renders the band again fused)
-    __device__ __forceinline__ uint32_t take(const ShadeArgs& a, uint32_t units, uint32_t lane) {
-        if (pos + units > end) {
-            uint32_t s = 0;
-            if (lane == 0) s = atomicAdd(a.pair_alloc, 1u);
-            s = __builtin_amdgcn_readfirstlane(s);
-            if (s >= a.pair_slabs) {
-                if (lane == 0) atomicAdd(&a.counters[CNT_OVERFLOW_PAIRS], 1ull);
-                return 0xFFFFFFFFu;
-            }
-            pos = s * a.pair_slab_units; end = pos + a.pair_slab_units;
-        }
-        const uint32_t off = pos;
-        pos += units;
-        return off;
-    }
-};
-
-// SPLIT: the kernel classifies and shades everything that needs no samples; for a (chunk, light) that does, it leaves
-// the rows and the light's slope as a record for k_shade_samples (ShadeArgs::pair_hdr) instead of running the sample
-// loop itself.  Without the registers of that loop the classification -- dependent chains, scalar loads, wave-wide
-// votes: bound by latency, not by issue -- runs with more waves per SIMD, and the sample loop, which is bound by issue,
-// runs in a kernel of its own whose waves do nothing else.  (No boxes in the split form: their per-sample slab
-// constants would make a record of 39 more values per lane.)
-template <bool ALL_OPAQUE, bool HAS_BOX, int SM, bool SPLIT>
+template <bool ALL_OPAQUE, bool HAS_BOX, int SM>
 #ifndef RT_LB_NOBOX
 #define RT_LB_NOBOX 3   // waves per SIMD the register budget is set for: 4 would spill ~250 bytes per lane and cost 25 % (measured)
 #endif
@@ -1186,11 +1148,7 @@ template <bool ALL_OPAQUE, bool HAS_BOX, int SM, bool SPLIT>
 #define RT_LB_BOX 2
 #endif
 
-#ifndef RT_LB_SPLIT
-#define RT_LB_SPLIT 4
-#endif
-__global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX))) void k_shade_fast(ShadeArgs a) {
-    static_assert(!SPLIT || !HAS_BOX, "sample records hold linear rows only");
+__global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT_LB_NOBOX)) void k_shade_fast(ShadeArgs a) {
     constexpr uint32_t MASK_SHIFT = 32 - SM;   // a deferred item packs (light | surfaces-in-reach mask << MASK_SHIFT)
     const uint32_t count = queue_slots(a.q);
     const int S = a.fp.n_surfaces, L = a.fp.n_lights, N = a.fp.n_shadow;
@@ -1212,7 +1170,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
     unsigned long long n_samples = 0;   // samples generated x lanes holding a hit (wave-uniform)
     ItemQueues items;
     items.init((count + 63u) >> 6, n_waves);
-    SlabCursor slab;
     for (;;) {
         uint32_t item;
         if (!items.next(a.work, lane, item)) break;
@@ -1221,12 +1178,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
         const uint32_t base = chunk << 6;
         HitRec h;
         bool active;
-        uint2* const hdr = SPLIT ? a.pair_hdr + (size_t)chunk * (size_t)(L + 1) : nullptr;
-        if (!load_chunk(a.q, base, count, lane, h, active)) {
-            if (SPLIT && lane == 0) hdr[L] = make_uint2(0u, 0u);   // nothing for the sampling kernel in this chunk
-            continue;
-        }
-        uint32_t n_records = 0;   // records left for the sampling kernel (wave-uniform)
+        if (!load_chunk(a.q, base, count, lane, h, active)) continue;
         const f3 P = h.P;
         const SurfF own_sf = a.surf[h.own_id];
         const MatF m = a.mat[own_sf.mat];
@@ -1264,8 +1216,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
         }
         double cx = 0.0, cy = 0.0, cz = 0.0;   // lights summed in float64 (see k_shade_general)
         for (int l = l_first; l < l_last; ++l) {
-            uint32_t rec_off = 0xFFFFFFFFu;   // SPLIT: this light's record (wave-uniform)
-            if (SPLIT && lane == 0) hdr[l] = make_uint2(0u, 0u);
             if (a.special && a.special[l] != a.special[l + 1]) {   // a light on a surface: the whole pair is shaded by k_shade_exact
                 list_pairs(a, active, base + lane, (uint32_t)l | RT_PAIR_FULL);
                 continue;
@@ -1469,31 +1419,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
                 }
                 if (!defer) {
                     wl_n[k + nb <= 4 ? k + nb : 4] += 1;
-                    if (SPLIT && k > 0) {
-                        // the rows, the grid's key and |lrel|^2 go to the sampling kernel (fields of 64 lanes: a wave
-                        // writes 256 bytes per store); the slope follows below, where the Phong terms are known
-                        const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
-                        constexpr uint32_t ROW_FIELDS = ALL_OPAQUE ? 3u : 4u;
-                        rec_off = slab.take(a, (5u + ROW_FIELDS * (uint32_t)k) * RT_PAIR_FIELD_UNITS, lane);
-                        if (rec_off != 0xFFFFFFFFu) {
-                            float* rec = a.pair_data + (size_t)rec_off * 4 + lane;
-                            rec[0] = __uint_as_float(key);
-                            rec[64] = lc2;
-                            float* rows = rec + 5 * 64;
-#pragma unroll
-                            for (int e = 0; e < KMAX; ++e) {
-                                if (e < k) {   // (wave-uniform)
-                                    rows[(e * ROW_FIELDS + 0) * 64] = (e & 1) ? R.AA[e >> 1].y : R.AA[e >> 1].x;
-                                    rows[(e * ROW_FIELDS + 1) * 64] = R.BC[e].x;
-                                    rows[(e * ROW_FIELDS + 2) * 64] = R.BC[e].y;
-                                    if (!ALL_OPAQUE) rows[(e * ROW_FIELDS + 3) * 64] = R.tr[e];
-                                }
-                            }
-                            if (lane == 0) hdr[l] = make_uint2(rec_off, (uint32_t)k);
-                            n_records += 1u;
-                        }
-                    }
-                    if (!SPLIT && k + nb > 0) {
+                    if (k + nb > 0) {
                         const uint32_t key = rt_grid_key(a.fp.seed_key, h.gpix, h.node, (uint32_t)l);
                         const float ku = RT_JITTER_INV * invN * lt.radius;  // 2^-8 / N * radius
                         const float koff = -0.5f * lt.radius;
@@ -1575,27 +1501,10 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
                 }
                 wl_n[lt.point_path ? 6 : 5] += 1;
             } else {
-                const PhongPair ph = phong_split(h.nrm, ldir, h.view, m, lt, h.wgt);   // need_exact lanes: k_shade_exact adds the correction
-                if (SPLIT && rec_off != 0xFFFFFFFFu) {   // (wave-uniform) the sampling kernel adds slope * ratio
-                    float* rec = a.pair_data + (size_t)rec_off * 4 + lane;
-                    rec[2 * 64] = ph.slope.x; rec[3 * 64] = ph.slope.y; rec[4 * 64] = ph.slope.z;
-                    cx += (double)ph.base.x; cy += (double)ph.base.y; cz += (double)ph.base.z;
-                } else {
-                    cx += phong_term(ph.base.x, ph.slope.x, ratio); cy += phong_term(ph.base.y, ph.slope.y, ratio); cz += phong_term(ph.base.z, ph.slope.z, ratio);
-                }
-            }
-        }
-        if (SPLIT) {
-            // a chunk with records hands its sums over with them: the sampling kernel adds its part and updates the pixel once
-            uint32_t blk_off = 0xFFFFFFFFu;
-            if (n_records) blk_off = slab.take(a, RT_PAIR_CHUNK_FIELDS * RT_PAIR_FIELD_UNITS, lane);
-            if (lane == 0) hdr[L] = blk_off != 0xFFFFFFFFu ? make_uint2(blk_off, n_records) : make_uint2(0u, 0u);
-            if (blk_off != 0xFFFFFFFFu) {
-                float* blk = a.pair_data + (size_t)blk_off * 4;
-                ((uint32_t*)blk)[lane] = active ? h.lpix : 0xFFFFFFFFu;
-                double* sums = (double*)(blk + 64);
-                sums[lane] = cx; sums[64 + lane] = cy; sums[128 + lane] = cz;
-                continue;
+                f3 term = F3(0.f, 0.f, 0.f);
+                const f3 wgt1 = h.wgt;
+                phong_add(term, h.nrm, ldir, h.view, m, lt, ratio);   // need_exact lanes: k_shade_exact adds the correction
+                cx += (double)(wgt1.x * term.x); cy += (double)(wgt1.y * term.y); cz += (double)(wgt1.z * term.z);
             }
         }
         if (active && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
@@ -1611,84 +1520,6 @@ __global__ __launch_bounds__(SHADE_BLOCK, SPLIT ? RT_LB_SPLIT : (SM > 8 ? 2 : (H
             if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
         if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
     }
-}
-
-// The sample loops of the records k_shade_fast<..., SPLIT> left (ShadeArgs::pair_hdr): one chunk with all its records per
-// work item; per record the rows come back into registers, the N x N grid is walked exactly as the fused kernel walks it
-// (compact_samples: tile decisions, packed sample pairs), and the light adds slope * ratio to the chunk's sums, which
-// update the pixel once.
-template <bool ALL_OPAQUE>
-#ifndef RT_LB_SAMPLES
-#define RT_LB_SAMPLES 4
-#endif
-__global__ __launch_bounds__(SHADE_BLOCK, RT_LB_SAMPLES) void k_shade_samples(ShadeArgs a) {
-    const uint32_t count = queue_slots(a.q);
-    const int L = a.fp.n_lights, N = a.fp.n_shadow;
-    const float invN = 1.0f / (float)N;
-    const float inv_n2 = 1.0f / (float)(N * N);
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t n_waves = (gridDim.x * SHADE_BLOCK) >> 6;
-    constexpr int ROW_FIELDS = ALL_OPAQUE ? 3 : 4;
-    unsigned long long n_samples = 0;
-    ItemQueues items;
-    items.init((count + 63u) >> 6, n_waves);
-    uint32_t chunk;
-    while (items.next(a.work5, lane, chunk)) {
-        const uint2* hdr = a.pair_hdr + (size_t)chunk * (size_t)(L + 1);
-        const uint2 ch = uniform_load(hdr + L);
-        if (ch.y == 0u) continue;
-        const float* blk = a.pair_data + (size_t)ch.x * 4;
-        const uint32_t lpix = ((const uint32_t*)blk)[lane];
-        const double* sums = (const double*)(blk + 64);
-        double cx = sums[lane], cy = sums[64 + lane], cz = sums[128 + lane];
-        const uint32_t n_active = (uint32_t)__popcll(__ballot(lpix != 0xFFFFFFFFu));
-        for (int l = 0; l < L; ++l) {
-            const uint2 hd = uniform_load(hdr + l);
-            const int k = (int)hd.y;
-            if (k == 0) continue;
-            const float* rec = a.pair_data + (size_t)hd.x * 4 + lane;
-            const uint32_t key = __float_as_uint(rec[0]);
-            const float lc2 = rec[64];
-            const f3 slope = F3(rec[2 * 64], rec[3 * 64], rec[4 * 64]);
-            Rows R;
-            R.clear();
-            const float* rows = rec + 5 * 64;
-#pragma unroll
-            for (int e = 0; e < KMAX; ++e) {
-                if (e < k) {   // (wave-uniform)
-                    const float ra = rows[(e * ROW_FIELDS + 0) * 64];
-                    R.BC[e] = F2(rows[(e * ROW_FIELDS + 1) * 64], rows[(e * ROW_FIELDS + 2) * 64]);
-                    if (e & 1) R.AA[e >> 1].y = ra; else R.AA[e >> 1].x = ra;
-                    if (!ALL_OPAQUE) R.tr[e] = rows[(e * ROW_FIELDS + 3) * 64];
-                }
-            }
-            const LightF lt = uniform_load(a.light + l);
-            const float ku = RT_JITTER_INV * invN * lt.radius;  // 2^-8 / N * radius
-            const float koff = -0.5f * lt.radius;
-            BoxSet bx;
-            float sum;
-            uint32_t n_gen = 0;
-            switch (k) {
-                case 1: sum = compact_samples<1, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 2: sum = compact_samples<2, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 3: sum = compact_samples<3, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 4: sum = compact_samples<4, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 5: sum = compact_samples<5, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 6: sum = compact_samples<6, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                case 7: sum = compact_samples<7, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-                default: sum = compact_samples<8, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
-            }
-            const float ratio = sum * inv_n2;
-            cx += (double)(slope.x * ratio); cy += (double)(slope.y * ratio); cz += (double)(slope.z * ratio);
-            n_samples += (unsigned long long)n_gen * n_active;
-        }
-        if (lpix != 0xFFFFFFFFu && (cx != 0.0 || cy != 0.0 || cz != 0.0)) {
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lpix], cx);
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lpix], cy);
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lpix], cz);
-        }
-    }
-    if (lane == 0 && n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
 }
 
 template <bool HAS_BOX, bool ALL_OPAQUE, int SM>
@@ -1920,13 +1751,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
         }
         const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
         if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_SAMPLES], (unsigned long long)(lt.point_path ? 1 : N * N) * n_active);
-        const PhongPair ph = phong_split(h.nrm, ldir, h.view, m, lt, h.wgt);
-        const double tx = phong_term(ph.base.x, ph.slope.x, ratio), ty = phong_term(ph.base.y, ph.slope.y, ratio), tz = phong_term(ph.base.z, ph.slope.z, ratio);
-        if (wv == 0 && active && (tx != 0.0 || ty != 0.0 || tz != 0.0)) {
+        f3 color = F3(0.f, 0.f, 0.f);
+        phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+        if (wv == 0 && active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
             const uint32_t lp = h.lpix;
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], tx);
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], ty);
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], tz);
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + lp], (double)(h.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + lp], (double)(h.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + lp], (double)(h.wgt.z * color.z));
         }
     }
 }
@@ -2034,12 +1865,12 @@ __device__ __forceinline__ void shade_pair_full(const ShadeArgs& a, uint32_t slo
         ratio = sum / (float)(N * N);
     }
     {
-        const PhongPair ph = phong_split(h.nrm, ldir, h.view, m, lt, h.wgt);
-        const double tx = phong_term(ph.base.x, ph.slope.x, ratio), ty = phong_term(ph.base.y, ph.slope.y, ratio), tz = phong_term(ph.base.z, ph.slope.z, ratio);
-        if (tx != 0.0 || ty != 0.0 || tz != 0.0) {
-            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], tx);
-            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], ty);
-            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], tz);
+        f3 color = F3(0.f, 0.f, 0.f);
+        phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
+        if (color.x != 0.f || color.y != 0.f || color.z != 0.f) {
+            unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], (double)(h.wgt.x * color.x));
+            unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], (double)(h.wgt.y * color.y));
+            unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(h.wgt.z * color.z));
         }
     }
 }
@@ -2122,11 +1953,13 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
                 for (int o = 32; o > 0; o >>= 1) delta += __shfl_down(delta, o);
                 if (lane == 0 && delta != 0.f) {
                     const MatF m = a.mat[own_sf.mat];
-                    const PhongPair ph = phong_split(h.nrm, ldir, h.view, m, lt, h.wgt);   // affine in the ratio: the slope times the
-                    const float dr = delta / (float)(N * N);                               // change of the ratio is the correction
-                    unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], (double)(ph.slope.x * dr));
-                    unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], (double)(ph.slope.y * dr));
-                    unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(ph.slope.z * dr));
+                    f3 c1 = F3(0.f, 0.f, 0.f), c0 = F3(0.f, 0.f, 0.f);
+                    phong_add(c1, h.nrm, ldir, h.view, m, lt, delta / (float)(N * N));   // affine in the ratio:
+                    phong_add(c0, h.nrm, ldir, h.view, m, lt, 0.f);                       // the difference is the correction
+                    const f3 color = c1 - c0;
+                    unsafeAtomicAdd(&a.accum[(size_t)0 * a.npix + h.lpix], (double)(h.wgt.x * color.x));
+                    unsafeAtomicAdd(&a.accum[(size_t)1 * a.npix + h.lpix], (double)(h.wgt.y * color.y));
+                    unsafeAtomicAdd(&a.accum[(size_t)2 * a.npix + h.lpix], (double)(h.wgt.z * color.z));
                 }
             }
         }
@@ -2160,30 +1993,15 @@ static int resident_blocks_per_cu(K kernel) {
 }
 
 template <int SM>
-static void launch_small(const ShadeArgs& a, int n_cu, dim3 g, dim3 b, hipStream_t s, hipEvent_t after_main, hipEvent_t after_classify) {
+static void launch_small(const ShadeArgs& a, int n_cu, dim3 g, dim3 b, hipStream_t s, hipEvent_t after_main) {
     static int occ[2][2] = {{0, 0}, {0, 0}};   // [has_box][all_opaque], filled on first use
     int& o = occ[a.has_box ? 1 : 0][a.all_opaque ? 1 : 0];
-    if (a.pair_hdr && !a.has_box && SM == 8) {
-        // classification and sampling as two launches (ShadeArgs::pair_hdr)
-        static int occ_c[2] = {0, 0}, occ_s[2] = {0, 0};
-        const int ao = a.all_opaque ? 1 : 0;
-        if (ao) {
-            if (!occ_c[1]) { occ_c[1] = resident_blocks_per_cu(k_shade_fast<true, false, 8, true>); occ_s[1] = resident_blocks_per_cu(k_shade_samples<true>); }
-            hipLaunchKernelGGL((k_shade_fast<true, false, 8, true>), dim3(n_cu * occ_c[1]), b, 0, s, a);
-            if (after_classify) (void)hipEventRecord(after_classify, s);
-            hipLaunchKernelGGL((k_shade_samples<true>), dim3(n_cu * occ_s[1]), b, 0, s, a);
-        } else {
-            if (!occ_c[0]) { occ_c[0] = resident_blocks_per_cu(k_shade_fast<false, false, 8, true>); occ_s[0] = resident_blocks_per_cu(k_shade_samples<false>); }
-            hipLaunchKernelGGL((k_shade_fast<false, false, 8, true>), dim3(n_cu * occ_c[0]), b, 0, s, a);
-            if (after_classify) (void)hipEventRecord(after_classify, s);
-            hipLaunchKernelGGL((k_shade_samples<false>), dim3(n_cu * occ_s[0]), b, 0, s, a);
-        }
-    } else if (a.has_box) {
-        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, true, SM, false>); hipLaunchKernelGGL((k_shade_fast<true, true, SM, false>), dim3(n_cu * o), b, 0, s, a); }
-        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, true, SM, false>); hipLaunchKernelGGL((k_shade_fast<false, true, SM, false>), dim3(n_cu * o), b, 0, s, a); }
+    if (a.has_box) {
+        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, true, SM>); hipLaunchKernelGGL((k_shade_fast<true, true, SM>), dim3(n_cu * o), b, 0, s, a); }
+        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, true, SM>); hipLaunchKernelGGL((k_shade_fast<false, true, SM>), dim3(n_cu * o), b, 0, s, a); }
     } else {
-        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, false, SM, false>); hipLaunchKernelGGL((k_shade_fast<true, false, SM, false>), dim3(n_cu * o), b, 0, s, a); }
-        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, false, SM, false>); hipLaunchKernelGGL((k_shade_fast<false, false, SM, false>), dim3(n_cu * o), b, 0, s, a); }
+        if (a.all_opaque) { if (!o) o = resident_blocks_per_cu(k_shade_fast<true, false, SM>); hipLaunchKernelGGL((k_shade_fast<true, false, SM>), dim3(n_cu * o), b, 0, s, a); }
+        else { if (!o) o = resident_blocks_per_cu(k_shade_fast<false, false, SM>); hipLaunchKernelGGL((k_shade_fast<false, false, SM>), dim3(n_cu * o), b, 0, s, a); }
     }
     if (after_main) (void)hipEventRecord(after_main, s);
     if (a.has_box) {
@@ -2198,7 +2016,7 @@ static void launch_small(const ShadeArgs& a, int n_cu, dim3 g, dim3 b, hipStream
 // Scenes of up to 8 surfaces use the register-resident kernels at full occupancy, 9..16 surfaces the same kernels
 // with twice the per-surface registers (two waves per SIMD; a deferred item then has 16 bits for the light), larger
 // scenes the any-size kernel.
-void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main, hipEvent_t after_classify) {
+void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t after_main) {
     const dim3 g(n_cu * 4), b(SHADE_BLOCK);
     const int S = a.fp.n_surfaces;
     if (a.variant == SHADE_GENERAL || S > 16 || (S > SMALL_MAX && a.fp.n_lights >= 65536)) {
@@ -2206,9 +2024,9 @@ void rt_launch_shade(const ShadeArgs& a, int n_cu, hipStream_t s, hipEvent_t aft
         else hipLaunchKernelGGL(k_shade_general<false>, g, b, 0, s, a);
         if (after_main) (void)hipEventRecord(after_main, s);
     } else if (S > SMALL_MAX) {
-        launch_small<16>(a, n_cu, g, b, s, after_main, after_classify);
+        launch_small<16>(a, n_cu, g, b, s, after_main);
     } else {
-        launch_small<SMALL_MAX>(a, n_cu, g, b, s, after_main, after_classify);
+        launch_small<SMALL_MAX>(a, n_cu, g, b, s, after_main);
     }
     hipLaunchKernelGGL(k_shade_exact, g, b, 0, s, a);
 }

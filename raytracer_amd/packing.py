@@ -47,7 +47,7 @@ class RtStats(C.Structure):
         ("bands", C.c_uint32), ("reserved", C.c_uint32),
         ("ms_total", C.c_double), ("ms_trace", C.c_double), ("ms_shade", C.c_double),
         ("ms_resolve", C.c_double), ("flop_shade", C.c_double), ("wave_light", C.c_uint64 * 8),
-        ("ms_shade_main", C.c_double), ("shadow_samples", C.c_uint64), ("ms_shade_samples", C.c_double),
+        ("ms_shade_main", C.c_double), ("shadow_samples", C.c_uint64),
     ]
 
     def as_dict(self):
