@@ -364,6 +364,59 @@ def test_grid_walk_matches_brute_force_on_a_crowded_scene(oracle, tmp_path, monk
         r.close()
 
 
+def _huge_scene_text(n_spheres=66000, n_boxes=4000, seed=11):
+    """More than 65 536 surfaces (surface indices beyond 16 bits in every table that holds one): small spheres and boxes
+    over a ground plane, a few transparent or reflecting; coordinates on a 2^-10 lattice so that the text round-trips."""
+    state = [seed * 2654435761 % 2**32]
+
+    def u():
+        state[0] = (state[0] * 1664525 + 1013904223) % 2**32
+        return (state[0] >> 8) / 16777216.0
+
+    def q(lo, hi):
+        return round((lo + (hi - lo) * u()) * 1024.0) / 1024.0
+
+    lines = ["cam 0 6 8  0 0 -15  0 1 0  1.2 1.8", "set 0.2 0.3 0.5 2 2",
+             "mtl 0.8 0.3 0.2  0.5 0.5 0.5  0 0 0  20 0", "mtl 0.2 0.7 0.3  0.5 0.5 0.5  0.3 0.3 0.3  10 0",
+             "mtl 0.3 0.3 0.9  0.5 0.5 0.5  0 0 0  30 0.5", "mtl 0.6 0.6 0.6  0.1 0.1 0.1  0 0 0  5 0", "pln 0 1 0 0 4"]
+    for _ in range(n_spheres):
+        r = q(0.05, 0.15)
+        lines.append(f"sph {q(-20, 20)!r} {round((r + q(0, 3)) * 1024) / 1024!r} {q(-45, 0)!r} {r!r} {1 + int(u() * 3)}")
+    for _ in range(n_boxes):
+        e = q(0.1, 0.3)
+        lines.append(f"box {q(-20, 20)!r} {round((e / 2 + q(0, 3)) * 1024) / 1024!r} {q(-45, 0)!r} {e!r} {1 + int(u() * 3)}")
+    lines += ["lgt 5 30 10  1 1 1  1 0.8 2", "lgt -8 25 -30  0.7 0.7 0.8  0.5 0.7 1.5"]
+    return "\n".join(lines) + "\n"
+
+
+def test_more_than_65536_surfaces(oracle, tmp_path):
+    """70 001 surfaces: the surface index leaves 16 bits everywhere it is stored (shade records, cell lists, the
+    per-light lists, the debug probe).  Queries bit for bit, counters and image against the oracle's file-order loop;
+    a 2 x 2 shadow grid per light, so the any-size shading kernel walks the grid with batched shadow rays too."""
+    sc = R.parse_scene_file(write_scene(tmp_path, _huge_scene_text()))
+    assert len(sc.surfaces) == 70001
+    w, h = 96, 54
+    r = runtime.Renderer(0)
+    try:
+        r.set_scene(sc)
+        _, u8, st = r.render_rows(w, h, seed=3)
+        ref, cnt = oracle.render_frame(sc, w, h, seed=3, threads=THREADS)
+        assert counters_of(st) == cnt
+        assert_parity(u8, ref)
+        xs, ys = grid_points(w, h)
+        _, _, oh = oracle.render_pixels(sc, w, h, xs, ys, seed=3, record_hits=True)
+        hb = r.debug_hits(w, h, capacity=len(oh) + 64)
+        assert hb["count"] == len(oh)
+        want = {(o[0], o[1]): o for o in oh}
+        for i in range(hb["count"]):
+            o = want[(int(hb["pixel"][i]), int(hb["node"][i]))]
+            assert (o[2], o[3]) == (hb["surf"][i], hb["t"][i])
+            assert o[4] == tuple(hb["P"][i]) and o[5] == tuple(hb["n"][i])
+        assert int(hb["surf"].max()) >= 65536      # the frame does see surfaces beyond 16 bits
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("name", ["cubes", "transparency_v7"])
 def test_grid_forced_on_small_scenes(oracle, monkeypatch, name):
     """RT_GRID=1 builds the grid for any scene; with RT_FLAG_GENERAL_SHADE the shadow rays walk it too."""
