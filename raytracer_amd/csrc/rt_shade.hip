@@ -750,6 +750,7 @@ __device__ __forceinline__ void box_values(const BoxSet& bx, float ur, float vr,
 
 // The linear rows of one (wave, light) pair as the packed sample loop wants them: (B, C) of a row in one register pair,
 // the A of rows 2e and 2e + 1 in another.  A lane that does not need a row holds an inert one (A = -inf, B = C = 0).
+#define RT_COUNT_SCALE 1073741824.0f   // 2^30: see compact_samples
 struct Rows {
     f2 BC[KMAX], AA[KMAX / 2];
     float tr[KMAX];   // transparency of the row's surface (scenes with transparent surfaces)
@@ -758,6 +759,11 @@ struct Rows {
         for (int e = 0; e < KMAX; ++e) { BC[e] = F2(0.f, 0.f); tr[e] = 1.f; }
 #pragma unroll
         for (int e = 0; e < KMAX / 2; ++e) AA[e] = F2(-INFINITY, -INFINITY);
+    }
+    // what compact_samples<K, 0, true, ...> (opaque scene, no boxes) expects of the rows it is given
+    __device__ __forceinline__ void scale_for_counting() {
+#pragma unroll
+        for (int e = 0; e < KMAX / 2; ++e) AA[e] = AA[e] * RT_COUNT_SCALE;
     }
     template <int E>
     __device__ __forceinline__ void set(float a, float b, float c, float t) {
@@ -775,6 +781,14 @@ __device__ __forceinline__ float vmax3_zero(float a, float b) { float d; asm("v_
 __device__ __forceinline__ f2 pk_sq_minus(f2 a, f2 c) {         // a * a - c
     f2 d; asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d;
 }
+// "nothing blocks" as a number: clamp(len^2 - m * m) and clamp(len^2 - m * |m|), 1 where the difference is >= 1 and 0 where
+// it is <= 0 -- exact for the sample loop's operands, which are scaled so that no difference lies in between
+__device__ __forceinline__ f2 pk_open_sq(f2 m, f2 len2) {       // m >= 0: both samples in one instruction
+    f2 d; asm("v_pk_fma_f32 %0, %1, %1, %2 neg_lo:[1,0,0] neg_hi:[1,0,0] clamp" : "=v"(d) : "v"(m), "v"(len2)); return d;
+}
+__device__ __forceinline__ float open_abs(float m, float len2) {
+    float d; asm("v_fma_f32 %0, -%1, |%1|, %2 clamp" : "=v"(d) : "v"(m), "v"(len2)); return d;
+}
 struct JitterWords4 { uint32_t w[4]; };   // the table words of the (up to) four sample pairs of one tile row
 
 // TABLE: the pair words come from the table in memory through the scalar unit (k_shade_fast: three waves per SIMD hide
@@ -784,6 +798,18 @@ struct JitterWords4 { uint32_t w[4]; };   // the table words of the (up to) four
 template <int K, int NB, bool ALL_OPAQUE, bool TABLE>
 __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint32_t* jitter_words, float ku, float koff, float lc2,
                                                  const Rows& R, const BoxSet& bx, uint32_t& n_generated) {
+    // Opaque scenes without boxes count the samples nothing blocks as numbers: the sign test  max(lin) * |max(lin)| - len^2 < 0
+    // becomes clamp(len^2 - max * |max|), added up in packed FP32 -- one instruction fewer per pair than shifting sign
+    // bits into a mask, and no popcount per row.  For the clamp to give exactly 0 or 1 every length is scaled by 2^30
+    // (the rows' A -- by the caller, Rows::scale_for_counting --, the cell edges and the jitter step; |lrel|^2 by 2^60):
+    // scaling by a power of two is exact, so every
+    // decision is the one the unscaled operands give, and the smallest non-zero difference the FMA can return -- one
+    // unit in the last place of the 48-bit product m * m, 2^-46 of len^2 -- is at least 1 for len^2 >= 2^-14 (the
+    // classification leaves lights nearer than 2^-7 to the generic kernel).  A plane's row (scaled by 2^60 already) overflows to an
+    // infinity in the product, which clamps to the right side.
+    constexpr bool COUNTED = ALL_OPAQUE && NB == 0;
+    constexpr float SCALE = COUNTED ? RT_COUNT_SCALE : 1.0f;
+    ku *= SCALE; koff *= SCALE; lc2 *= SCALE * SCALE;
     // The grid is walked in tiles of T x T cells.  Every entry is affine in (ur, vr) minus len, so its range over a
     // tile's rectangle follows from the corners; when, for every lane of the wave, either no entry can block anywhere
     // in the tile or (opaque scenes) one entry blocks everywhere, the tile's samples are not generated at all (the
@@ -818,7 +844,7 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
             const float hi = Ae + fmaxf(bu0, bu1) + fmaxf(cv0, cv1) - len_lo;
             const float lo = Ae + fminf(bu0, bu1) + fminf(cv0, cv1) - len_hi;
             // (an inert row, A = -inf, must come out as "cannot block": its margin stays finite)
-            const float margin = 1e-5f * (fminf(fabsf(Ae), 1e30f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
+            const float margin = 1e-5f * (fminf(fabsf(Ae), 1e36f) + fmaxf(fabsf(bu0), fabsf(bu1)) + fmaxf(fabsf(cv0), fabsf(cv1)) + len_hi);
             can_block = can_block || !(hi < -margin);   // (also true for NaN: never skip on doubt)
             must_block = must_block || lo > margin;
         }
@@ -866,10 +892,12 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
             const uint32_t* wp = jitter_words + (uint32_t)i0 * stride + ((uint32_t)j0 >> 1);
             JitterWords4 words{}, words_next{};
             if (TABLE) words = uniform_load((const JitterWords4*)wp);
+            f2 open2 = F2(0.f, 0.f);   // COUNTED: open samples of the tile (.x even columns, .y odd ones)
             for (int i = i0; i < i1; ++i) {
                 wp += stride;
                 if (TABLE) words_next = uniform_load((const JitterWords4*)wp);
                 uint32_t mask = 0;
+                f2 last_open = F2(0.f, 0.f);
                 const f2 UL = F2(fmaf((float)i, cell, koff), lc2);  // (left edge of row i, |lrel|^2)
                 f2 vcol = vcol0;
                 float row_sum = 0.f;
@@ -883,10 +911,28 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
                         const f2 vr = pk_fma_bL(vb, KU, vcol);
                         vcol = pk_add_bH(vcol, KU);
                         const f2 len2 = pk_fma(ur, ur, pk_fma_cH(vr, vr, UL));
-                        if (ALL_OPAQUE) {
-                            // any entry blocks  <=>  the largest lin reaches len: lin >= len  <=>  lin * |lin| - len^2 >= 0.
-                            // With an even number of rows the last maximum takes a zero along for free, and a value
-                            // that is not negative needs no |.|: both samples' residues in one packed instruction.
+                        if (COUNTED) {
+                            // any entry blocks  <=>  the largest lin reaches len.  With an even number of rows the last
+                            // maximum takes a zero along for free, and a value that is not negative needs no |.|: both
+                            // samples in one packed instruction.
+                            f2 vm = row_pair(0, ur, vr);
+#pragma unroll
+                            for (int e = 1; e + 1 < K - (K % 2 == 0 ? 1 : 0); e += 2) {
+                                const f2 l1 = row_pair(e, ur, vr), l2 = row_pair(e + 1, ur, vr);
+                                vm.x = vmax3(vm.x, l1.x, l2.x); vm.y = vmax3(vm.y, l1.y, l2.y);
+                            }
+                            f2 open;
+                            if (K % 2 == 0) {
+                                const f2 l1 = row_pair(K - 1, ur, vr);
+                                vm.x = vmax3_zero(vm.x, l1.x); vm.y = vmax3_zero(vm.y, l1.y);
+                                open = pk_open_sq(vm, len2);
+                            } else {
+                                open.x = open_abs(vm.x, len2.x); open.y = open_abs(vm.y, len2.y);
+                            }
+                            open2 += open;
+                            last_open = open;
+                        } else if (ALL_OPAQUE) {
+                            // (with boxes: the sign test lin * |lin| - len^2 >= 0, the boxes' values beside it)
                             f2 res = F2(-INFINITY, -INFINITY);
                             if (K > 0) {
                                 f2 vm = row_pair(0, ur, vr);
@@ -936,12 +982,15 @@ __device__ __forceinline__ float compact_samples(int N, uint32_t key, const uint
                         }
                     }
                 }
-                if (ALL_OPAQUE) {
+                if (COUNTED) {
+                    if (odd_tail) open2.y -= last_open.y;   // (wave-uniform) the second sample of the row's last pair does not exist
+                } else if (ALL_OPAQUE) {
                     if (odd_tail) mask &= ~1u;   // the bit shifted in last belongs to no sample
                     open_samples += (uint32_t)__popc(mask);
                 } else sum += row_sum;
                 if (TABLE) words = words_next;
             }
+            if (COUNTED) open_samples += (uint32_t)(open2.x + open2.y);   // (at most 64: exact)
         }
     }
     return ALL_OPAQUE ? (float)open_samples : sum;
@@ -1014,7 +1063,7 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
     const bool own_sphere = own_valid && own_sf.type == RT_SURF_SPHERE;
     const f3 ov = P - F3(own_sf.a.x, own_sf.a.y, own_sf.a.z);
     float A[KMAX + 1], B[KMAX + 1], C[KMAX + 1], tr[KMAX + 1];
-    bool gen = false;
+    bool gen = llen < 0.0078125f;   // (as in k_shade_fast: the counted sample loop wants the light at least 2^-7 away)
     uint32_t lin = 0;
     unsigned long long rem = reach_mask;
 #pragma unroll
@@ -1122,6 +1171,7 @@ __device__ __forceinline__ bool linear_wave_ratio(const ShadeArgs& a, const HitR
                  //  registers of their sample loops cost this kernel more than the generic loop costs the few waves)
     const int kk = k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8));   // (spare rows are inert)
     if (a.all_opaque) {
+        R.scale_for_counting();
         switch (kk) {
             case 1: sum = compact_samples<1, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
             case 2: sum = compact_samples<2, 0, true, false>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
@@ -1271,7 +1321,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                     }
                     k += 1;
                 };
-                bool gen = false;
+                // (a light within 2^-7 of the hit: the counted sample loop wants |sample - hit|^2 >= 2^-19, see compact_samples)
+                bool gen = llen < 0.0078125f;
                 uint32_t reach_bits = 0, box_bits = 0;
 #pragma unroll
                 for (int j = 0; j < SM; ++j) {
@@ -1460,6 +1511,7 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
                         float sum;
                         uint32_t n_gen = 0;
                         if (!HAS_BOX || nb == 0) {
+                            if (ALL_OPAQUE) R.scale_for_counting();
                             switch (k) {
                                 case 1: sum = compact_samples<1, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
                                 case 2: sum = compact_samples<2, 0, ALL_OPAQUE, true>(N, key, a.jitter_words, ku, koff, lc2, R, bx, n_gen); break;
