@@ -46,7 +46,8 @@ constexpr size_t kMinArenaPixels = 65536;
 constexpr int kAsyncFirst = 32;        // bookkeeping entries (events + pinned counters) made at the first rt_render_enqueue
 constexpr int kAsyncMax = 1024;        // frames rt_render_enqueue keeps in flight before it waits for the oldest one
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
-constexpr int kQCounts = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
+constexpr int kTailWork = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);   // tile counter of k_trace_tail, on a line of its own
+constexpr int kQCounts = kTailWork + (int)RT_WORK_QUEUE_STRIDE;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 constexpr size_t kHostRows = 16384;    // rows of the pinned row-list staging buffer made at rt_create (grows on demand)
 
@@ -395,6 +396,17 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         ta.accum = h->fm.d_accum; ta.npix = pixels; ta.counters = h->d_counters; ta.depth = d;
         if (d == tail_from) {
             ta.stack = h->fm.stack; ta.stack_levels = h->both_children ? (uint32_t)h->R : 0u;
+            {   // what the workgroups reserve without using (less than two reservations each) stays below an eighth of the room
+                const size_t room = (size_t)h->fm.sq.capacity > slots0 ? (size_t)h->fm.sq.capacity - slots0 : 0;
+                size_t rsv = RT_TAIL_RESERVE;
+                while (rsv > 64 && rsv * 16 * (size_t)tail_blocks > room) rsv /= 2;
+                ta.tail_reserve = (uint32_t)rsv;
+            }
+            // tiles from a shared counter when a workgroup's equal share would be fewer than 16 eights of tiles (measured:
+            // 1080p frames gain up to 12 %, 4K frames lose as much to the counter's round trips)
+            // (a launch that starts below the camera rays -- a test hook -- does not know its item count here)
+            const bool few = d > 0 || slots0 / ((size_t)RT_TAIL_BLOCK * 16) < (size_t)tail_blocks;
+            ta.work = few ? h->d_qcounts + kTailWork : nullptr;
             rt_launch_trace_tail(ta, tail_blocks, st);
             break;
         }
@@ -549,7 +561,9 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
                 // counted, not written): enlarge the arena to what this band needs and render it again in one piece.
                 // The arena stays that large, so the following frames of the scene do not pay for the discovery again
                 // (a deep ray tree over a 4K band needs a few GB out of 288).
-                const size_t slots = (size_t)h->fm.sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE];
+                // (+ what the ray-tree kernel's workgroups reserve without using: at most twice RT_TAIL_RESERVE slots each)
+                const size_t slots = (size_t)h->fm.sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE] +
+                                     (size_t)h->n_cu * 2 * 2 * RT_TAIL_RESERVE;
                 const size_t need = (slots + slots / 8 + kShadeFactor - 1) / kShadeFactor;
                 if (need <= kMaxArenaPixels && need > h->fm.band_capacity) {
                     rc = ensure_band_capacity(h, need);

@@ -8,6 +8,7 @@
 #define RT_EPSF 1e-6f
 #define RT_TRACE_BLOCK 512  // threads per workgroup of the ray-tree kernel
 #define RT_TAIL_BLOCK 512   // threads per workgroup of its run-to-completion variant
+#define RT_TAIL_RESERVE 1024u   // shade-queue slots one of its workgroups reserves at a time, at most
 #define RT_SURF_TILE 512    // surfaces staged in LDS at a time (512 x 64 B = 32 KiB)
 
 // ---- float64 surface record used by the ray-tree kernel -------------------------
@@ -189,6 +190,8 @@ struct TraceArgs {
     int depth;
     RayQueue stack;        // tail kernel only: parked children, [level][thread]; tp.w = depth of the parked ray
     uint32_t stack_levels; // slots per thread (0: the scene has no material with both children)
+    uint32_t tail_reserve; // tail kernel only: shade-queue slots a workgroup reserves at a time (a multiple of 64)
+    uint32_t* work;        // tail kernel only: tiles handed out so far beyond each wave's (workgroup's) first one; zero at launch
 };
 void rt_launch_trace(const TraceArgs& a, int blocks, hipStream_t s);
 // follows every ray of a.in (or every camera ray when a.depth == 0) to the recursion limit; needs a.grid, or n_surfaces <= RT_SURF_TILE

@@ -175,12 +175,31 @@ __device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD*
     };
     setup(0, ix, sx, mx, ex); setup(1, iy, sy, my, ey); setup(2, iz, sz, mz, ez);
     const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
+    // FP32 pre-test per candidate (the shadow walk of the shading kernels has the same one): the ray against the list
+    // entry's bounding sphere, from a local origin where the ray enters the cell.  The entry's bounds sit beside its
+    // index, so a sure miss costs one 16-byte load and a dozen FP32 operations instead of the dependent load of the
+    // 64-byte surface record and its float64 test.  Directions are unit vectors up to rounding (camera rays are
+    // normalised, children reflect or continue them), which the margin proportional to |c - o| covers.
+    const float wx = (float)d.x, wy = (float)d.y, wz = (float)d.z;
+    double t_enter = t0;
     for (int it = 0; it < max_steps; ++it) {
         const uint32_t c = (uint32_t)((iz * g.n[1] + iy) * g.n[0] + ix);
         const uint32_t k1 = g.cell_start[c + 1];
-        for (uint32_t k = g.cell_start[c]; k < k1; ++k) { const int j = (int)g.items[k]; grid_candidate(surf[j], j, o, d, best, bs, bcode); }
+        const float olx = (float)fma(d.x, t_enter, o.x), oly = (float)fma(d.y, t_enter, o.y), olz = (float)fma(d.z, t_enter, o.z);
+        const float eps_cell = 3e-7f * (fabsf(olx) + fabsf(oly) + fabsf(olz)) + 1e-7f;
+        for (uint32_t k = g.cell_start[c]; k < k1; ++k) {
+            const float4 bnd = g.item_bounds[k];
+            const float cx = bnd.x - olx, cy = bnd.y - oly, cz = bnd.z - olz;
+            const float bb = fmaf(cz, wz, fmaf(cy, wy, cx * wx));
+            const float qx = fmaf(-wx, bb, cx), qy = fmaf(-wy, bb, cy), qz = fmaf(-wz, bb, cz);
+            const float rm = bnd.w + eps_cell + 2e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
+            if (fmaf(qz, qz, fmaf(qy, qy, qx * qx)) > rm * rm * 1.0001f) continue;   // (NaN: not skipped)
+            const int j = (int)g.items[k];
+            grid_candidate(surf[j], j, o, d, best, bs, bcode);
+        }
         const double t_exit = fmin(mx, fmin(my, mz));
         if (best < t_exit - 1e-9 * (1.0 + fabs(t_exit))) return;
+        t_enter = t_exit;
         if (mx <= my && mx <= mz) { ix += sx; if (ix < 0 || ix >= g.n[0]) return; mx += ex; }
         else if (my <= mz) { iy += sy; if (iy < 0 || iy >= g.n[1]) return; my += ey; }
         else { iz += sz; if (iz < 0 || iz >= g.n[2]) return; mz += ez; }
@@ -474,11 +493,21 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 // serialise on the counter word).  Needs the whole surface list in one LDS tile, or the grid.
 // ---------------------------------------------------------------------------------------
 #define TAIL_BLOCK RT_TAIL_BLOCK
+#ifndef TAIL_DYNAMIC
+#define TAIL_DYNAMIC 1
+#endif
 template <bool PRIMARY, bool GRID>
-__global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
+__global__ __launch_bounds__(TAIL_BLOCK, 4) void k_trace_tail(TraceArgs a) {   // (two workgroups per CU: at most 128 registers)
     __shared__ SurfD tile[SURF_TILE];
     __shared__ uint32_t s_cnt[TAIL_BLOCK / 64];
     __shared__ uint32_t s_base;
+    // Slots for appended hits are reserved a.tail_reserve at a time and handed out from LDS: returning atomics on one word
+    // complete at ~90 M/s on this chip whoever issues them, and one per workgroup and step is more than that allows.
+    // [s_free, s_end) is what the workgroup still holds; what a reservation leaves over, and the rest at the end, is
+    // marked as holding no hit (the shading kernels skip such slots like the camera rays that left the scene).
+    __shared__ uint32_t s_free, s_end, s_hole0, s_hole1;
+    if (threadIdx.x == 0) { s_free = 0; s_end = 0; s_hole0 = 0; s_hole1 = 0; }
+    __syncthreads();
     const int S = a.fp.n_surfaces, W = a.fp.width;
     uint32_t count;
     if (PRIMARY) count = primary_slots(a);
@@ -500,8 +529,17 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     // serves the shared slot reservation below).  In small scenes the whole workgroup finishes its eight tiles before
     // it takes the next eight: letting waves (or single lanes) run ahead was measured -- the ray trees get up to 13 %
     // faster, but the appended hits then arrive in an order that costs the register-resident shading kernel more.
-    uint32_t next_tile = blockIdx.x * (TAIL_BLOCK / 64) + wv;
-    const uint32_t tile_stride = gridDim.x * (TAIL_BLOCK / 64);
+    // There, the eights after the first come from a shared counter (ray trees differ in length by an order of magnitude
+    // between regions of a frame, so equal shares of tiles are unequal shares of work).  The counter is read one refill
+    // ahead: the atomic's round trip overlaps the ray trees of the current tiles.
+    constexpr uint32_t WAVES = TAIL_BLOCK / 64;
+    __shared__ uint32_t s_batch;
+    uint32_t next_tile = blockIdx.x * WAVES + wv;
+    // (grid scenes: a wave takes its tiles alone, one atomic per tile would be too many; frames with many eights per
+    // workgroup are balanced well enough by equal shares, and the launch then passes no counter)
+    const bool DYNAMIC = !GRID && TAIL_DYNAMIC && a.work != nullptr;
+    uint32_t ahead = 0;        // thread 0: counter value fetched for the workgroup's next refill
+    bool exhausted = false;    // DYNAMIC: the last refill found the tiles used up
     uint32_t idx = 0;
     bool have = false;
     d3 o = D3(0, 0, 0), d = D3(0, 0, 1);
@@ -513,7 +551,10 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
     {
         auto refill = [&]() {
             idx = next_tile * 64u + lane;
-            next_tile += tile_stride;
+            if (DYNAMIC) {   // (the caller sets next_tile from the counter value fetched here)
+                exhausted = (uint64_t)(next_tile - wv) * 64u >= count;
+                if (threadIdx.x == 0) ahead = atomicAdd(a.work, 1u);
+            } else next_tile += gridDim.x * WAVES;
             have = idx < count;
             tr = 1.f; tg = 1.f; tb = 1.f;
             lpix = 0; node = 1; gpix = 0;
@@ -535,6 +576,7 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             first = PRIMARY;
             if (PRIMARY && !have && idx < count) a.shade.r3[idx] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);  // slot outside the band
         };
+        if (DYNAMIC) refill();   // the workgroup's first eight tiles are its own
         for (;;) {
             // (a tile may hold no ray at all: pixels outside the band)
             if (GRID) {
@@ -542,7 +584,13 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             }
             if (!__syncthreads_or(have)) {
                 // small scenes: the workgroup moves on as a whole (all its waves advance together, so the test is uniform)
-                if (GRID || (uint64_t)(next_tile - wv) * 64u >= count) break;
+                if (GRID) break;
+                if (DYNAMIC) {
+                    if (exhausted) break;
+                    if (threadIdx.x == 0) s_batch = gridDim.x + ahead;
+                    __syncthreads();
+                    next_tile = s_batch * WAVES + wv;
+                } else if ((uint64_t)(next_tile - wv) * 64u >= count) break;
                 refill();
             } else {
             double best = INFINITY;
@@ -575,9 +623,19 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
                 uint32_t total = 0;
 #pragma unroll
                 for (int w = 0; w < TAIL_BLOCK / 64; ++w) { const uint32_t c = s_cnt[w]; s_cnt[w] = total; total += c; }
-                s_base = total ? atomicAdd(a.shade.count, total) : 0u;
+                uint32_t fr = s_free, en = s_end;
+                s_hole0 = fr; s_hole1 = fr;
+                if (total > en - fr) {
+                    s_hole1 = en;   // too small for this step: given up
+                    const uint32_t want = total > a.tail_reserve ? ((total + 63u) & ~63u) : a.tail_reserve;
+                    fr = atomicAdd(a.shade.count, want);
+                    en = fr + want;
+                }
+                s_base = fr; s_free = fr + total; s_end = en;
             }
             __syncthreads();
+            for (uint32_t hs = s_hole0 + threadIdx.x; hs < s_hole1; hs += TAIL_BLOCK)
+                if (a.shade.base + hs < a.shade.capacity) a.shade.r3[a.shade.base + hs] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
             const uint32_t slot_s = a.shade.base + s_base + s_cnt[wv] + __builtin_amdgcn_mbcnt_hi((uint32_t)(bs_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bs_, 0u));
             if (push_s) {
                 if (slot_s < a.shade.capacity) {
@@ -626,6 +684,8 @@ __global__ __launch_bounds__(TAIL_BLOCK) void k_trace_tail(TraceArgs a) {
             }
         }
     }
+    for (uint32_t hs = s_free + threadIdx.x; hs < s_end; hs += TAIL_BLOCK)   // (the loop is left by the whole workgroup, after a barrier)
+        if (a.shade.base + hs < a.shade.capacity) a.shade.r3[a.shade.base + hs] = make_uint4(0u, 0u, 0u, RT_NULL_HIT);
     unsigned long long s_tr = wave_sum(n_traced), s_cut = wave_sum(n_cut), s_sh = wave_sum(n_shaded);
     unsigned long long s_or = wave_sum(ovf_ray), s_os = wave_sum(ovf_shade);
     unsigned long long s_pr = wave_sum(n_primary);
