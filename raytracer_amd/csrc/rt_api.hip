@@ -283,7 +283,7 @@ void point_tail_stack(rt_handle* h, void* mem, size_t slots) {
 // smaller when nothing may be allocated (the launch then covers the band in more passes).
 int ensure_tail_stack(rt_handle* h, int& blocks) {
     if (!h->both_children) return RT_OK;  // no hit can park a child: the kernel gets stack_levels = 0
-    const size_t per_block = (size_t)RT_TAIL_BLOCK * (size_t)std::max(h->R, 1);
+    const size_t per_block = (size_t)(h->grid.cell_start ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK) * (size_t)std::max(h->R, 1);
     if ((size_t)blocks * per_block <= h->fm.stack_slots) return RT_OK;
     if (h->no_alloc) {
         blocks = (int)std::min<size_t>((size_t)blocks, h->fm.stack_slots / per_block);
@@ -383,7 +383,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     const int max_blocks = h->n_cu * 2;  // 512-thread workgroups: two are resident per CU, the loop is grid-stride
     const int depths = h->R > 0 ? h->R : 1;  // R == 0: one launch that writes the background
     const int tail_from = choose_tail_depth(h, depths);
-    int tail_blocks = h->n_cu * 2;
+    int tail_blocks = h->n_cu * (h->grid.cell_start ? RT_TAIL_PER_CU_GRID : RT_TAIL_PER_CU);
     if (tail_from < depths) { int rc = ensure_tail_stack(h, tail_blocks); if (rc != RT_OK) return rc; }
     for (int d = 0; d < depths && d <= tail_from; ++d) {
         TraceArgs ta{};
@@ -405,7 +405,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
             // tiles from a shared counter when a workgroup's equal share would be fewer than 16 eights of tiles (measured:
             // 1080p frames gain up to 12 %, 4K frames lose as much to the counter's round trips)
             // (a launch that starts below the camera rays -- a test hook -- does not know its item count here)
-            const bool few = d > 0 || slots0 / ((size_t)RT_TAIL_BLOCK * 16) < (size_t)tail_blocks;
+            const bool few = d > 0 || slots0 / ((size_t)RT_TAIL_BLOCK * 16) < (size_t)tail_blocks;   // (the grid variant ignores it)
             ta.work = few ? h->d_qcounts + kTailWork : nullptr;
             rt_launch_trace_tail(ta, tail_blocks, st);
             break;
@@ -563,7 +563,7 @@ int render_impl(rt_handle* h, const rt_render_params* p, float* d_f32, uint8_t* 
                 // (a deep ray tree over a 4K band needs a few GB out of 288).
                 // (+ what the ray-tree kernel's workgroups reserve without using: at most twice RT_TAIL_RESERVE slots each)
                 const size_t slots = (size_t)h->fm.sq.base + (size_t)br.c[CNT_SHADED] + (size_t)br.c[CNT_OVERFLOW_SHADE] +
-                                     (size_t)h->n_cu * 2 * 2 * RT_TAIL_RESERVE;
+                                     (size_t)h->n_cu * (h->grid.cell_start ? RT_TAIL_PER_CU_GRID : RT_TAIL_PER_CU) * 2 * RT_TAIL_RESERVE;
                 const size_t need = (slots + slots / 8 + kShadeFactor - 1) / kShadeFactor;
                 if (need <= kMaxArenaPixels && need > h->fm.band_capacity) {
                     rc = ensure_band_capacity(h, need);
@@ -675,9 +675,22 @@ int build_grid(rt_handle* h, const std::vector<SurfD>& sd, int S) {
         for (int q = 0; q < 3; ++q) bounds[k * 4 + q] = (float)c[q];
         bounds[k * 4 + 3] = (float)((r + off) * (1.0 + 1e-6) + 1e-9) * 1.000001f;
     }
-    const size_t words = bounds.size() + start.size() + items.size() + std::max<size_t>(global_items.size(), 1);
+    // per-cell records (SceneGrid::cell_rec)
+    std::vector<uint32_t> rec(cells * 16, 0u);
+    for (size_t c = 0; c < cells; ++c) {
+        const uint32_t k0 = start[c], n = start[c + 1] - start[c];
+        uint32_t* r = rec.data() + c * 16;
+        r[0] = n;
+        for (uint32_t e = 0; e < 3; ++e) {
+            r[1 + e] = e < n ? items[k0 + e] : 0xFFFFFFFFu;
+            if (e < n) std::memcpy(r + 4 + 4 * e, bounds.data() + (size_t)(k0 + e) * 4, 16);
+        }
+    }
+    const size_t words = rec.size() + bounds.size() + start.size() + items.size() + std::max<size_t>(global_items.size(), 1);
     HIP_TRY(h, hipMalloc(&h->d_grid_mem, words * sizeof(uint32_t)));
     uint32_t* p = h->d_grid_mem;
+    HIP_TRY(h, hipMemcpy(p, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    g.cell_rec = (const uint4*)p; p += rec.size();   // (first: 64-byte records on 64-byte boundaries)
     HIP_TRY(h, hipMemcpy(p, bounds.data(), bounds.size() * sizeof(float), hipMemcpyHostToDevice));
     g.item_bounds = (const float4*)p; p += bounds.size();   // (first: the allocation is 16-byte aligned)
     HIP_TRY(h, hipMemcpy(p, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice));

@@ -7,7 +7,15 @@
 #define RT_EPS 1e-6   // /root/reference/utils.py:6
 #define RT_EPSF 1e-6f
 #define RT_TRACE_BLOCK 512  // threads per workgroup of the ray-tree kernel
-#define RT_TAIL_BLOCK 512   // threads per workgroup of its run-to-completion variant
+// its run-to-completion variant: threads per workgroup, workgroups per CU and waves per SIMD its registers are budgeted
+// for -- scenes whose surface list is staged in LDS / scenes walked through the grid (a wave takes its tiles alone there:
+// single-wave workgroups wait for nobody, and three waves per SIMD leave the walk its registers)
+#define RT_TAIL_BLOCK 512
+#define RT_TAIL_PER_CU 2
+#define RT_TAIL_WAVES 4
+#define RT_TAIL_BLOCK_GRID 64
+#define RT_TAIL_PER_CU_GRID 12
+#define RT_TAIL_WAVES_GRID 3
 #define RT_TAIL_RESERVE 1024u   // shade-queue slots one of its workgroups reserves at a time, at most
 #define RT_SURF_TILE 512    // surfaces staged in LDS at a time (512 x 64 B = 32 KiB)
 
@@ -55,6 +63,10 @@ struct SceneGrid {
     // one bounding sphere per entry of `items` (centre xyz, radius; FP32, the radius grown by the rounding of the
     // centre): a ray that stays clear of it cannot meet the surface, which the walks test before they load the surface
     const float4* item_bounds;
+    // one 64-byte record per cell: {entries in the cell, index of entry 0, 1, 2} and the bounds of those three entries --
+    // what a walk needs of most cells in ONE round trip (cell_start -> item_bounds -> items are three dependent ones);
+    // entries from the fourth on are read from the lists above
+    const uint4* cell_rec;
 };
 
 struct MatF {

@@ -176,25 +176,33 @@ __device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD*
     setup(0, ix, sx, mx, ex); setup(1, iy, sy, my, ey); setup(2, iz, sz, mz, ez);
     const int max_steps = g.n[0] + g.n[1] + g.n[2] + 3;
     // FP32 pre-test per candidate (the shadow walk of the shading kernels has the same one): the ray against the list
-    // entry's bounding sphere, from a local origin where the ray enters the cell.  The entry's bounds sit beside its
-    // index, so a sure miss costs one 16-byte load and a dozen FP32 operations instead of the dependent load of the
-    // 64-byte surface record and its float64 test.  Directions are unit vectors up to rounding (camera rays are
-    // normalised, children reflect or continue them), which the margin proportional to |c - o| covers.
+    // entry's bounding sphere, from a local origin where the ray enters the cell.  A sure miss costs a dozen FP32
+    // operations instead of the dependent load of the 64-byte surface record and its float64 test.  Directions are unit
+    // vectors up to rounding (camera rays are normalised, children reflect or continue them), which the margin
+    // proportional to |c - o| covers.  The first three entries of a cell come with the cell's record (one round trip).
     const float wx = (float)d.x, wy = (float)d.y, wz = (float)d.z;
     double t_enter = t0;
     for (int it = 0; it < max_steps; ++it) {
         const uint32_t c = (uint32_t)((iz * g.n[1] + iy) * g.n[0] + ix);
-        const uint32_t k1 = g.cell_start[c + 1];
+        const uint4* rec = g.cell_rec + (size_t)c * 4;
+        const uint4 hd = rec[0];
+        const uint4 r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const uint32_t n = hd.x;
         const float olx = (float)fma(d.x, t_enter, o.x), oly = (float)fma(d.y, t_enter, o.y), olz = (float)fma(d.z, t_enter, o.z);
         const float eps_cell = 3e-7f * (fabsf(olx) + fabsf(oly) + fabsf(olz)) + 1e-7f;
-        for (uint32_t k = g.cell_start[c]; k < k1; ++k) {
-            const float4 bnd = g.item_bounds[k];
+        uint32_t k0 = 0;
+        if (n > 3) k0 = g.cell_start[c];
+        for (uint32_t e = 0; e < n; ++e) {
+            uint4 rb = e == 0 ? r1 : (e == 1 ? r2 : r3);
+            uint32_t ju = e == 0 ? hd.y : (e == 1 ? hd.z : hd.w);
+            if (e > 2) { rb = ((const uint4*)g.item_bounds)[k0 + e]; ju = g.items[k0 + e]; }
+            const float4 bnd = make_float4(__uint_as_float(rb.x), __uint_as_float(rb.y), __uint_as_float(rb.z), __uint_as_float(rb.w));
             const float cx = bnd.x - olx, cy = bnd.y - oly, cz = bnd.z - olz;
             const float bb = fmaf(cz, wz, fmaf(cy, wy, cx * wx));
             const float qx = fmaf(-wx, bb, cx), qy = fmaf(-wy, bb, cy), qz = fmaf(-wz, bb, cz);
             const float rm = bnd.w + eps_cell + 2e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz));
             if (fmaf(qz, qz, fmaf(qy, qy, qx * qx)) > rm * rm * 1.0001f) continue;   // (NaN: not skipped)
-            const int j = (int)g.items[k];
+            const int j = (int)ju;
             grid_candidate(surf[j], j, o, d, best, bs, bcode);
         }
         const double t_exit = fmin(mx, fmin(my, mz));
@@ -488,16 +496,17 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 // lane follow each other without queue round trips.  A hit with two children continues with
 // the reflection child and parks the transparency child on the lane's stack (one slot per
 // level, laid out [level][thread] so a wave's accesses stay contiguous).  All rays of a lane's
-// subtree belong to one pixel.  The workgroup steps through the levels together so that shade
-// records are reserved with ONE atomic per workgroup and step (per-wave reservations would
-// serialise on the counter word).  Needs the whole surface list in one LDS tile, or the grid.
+// subtree belong to one pixel.  The workgroup steps through the levels together and hands out
+// shade slots from a block it reserved with one atomic (reservations per wave and step would
+// serialise on the counter word).  Needs the whole surface list in one LDS tile (512-thread
+// workgroups), or the grid (single-wave workgroups: every wave takes its tiles alone).
 // ---------------------------------------------------------------------------------------
-#define TAIL_BLOCK RT_TAIL_BLOCK
 #ifndef TAIL_DYNAMIC
 #define TAIL_DYNAMIC 1
 #endif
 template <bool PRIMARY, bool GRID>
-__global__ __launch_bounds__(TAIL_BLOCK, 4) void k_trace_tail(TraceArgs a) {   // (two workgroups per CU: at most 128 registers)
+__global__ __launch_bounds__(GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK, GRID ? RT_TAIL_WAVES_GRID : RT_TAIL_WAVES) void k_trace_tail(TraceArgs a) {
+    constexpr int TAIL_BLOCK = GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK;
     __shared__ SurfD tile[SURF_TILE];
     __shared__ uint32_t s_cnt[TAIL_BLOCK / 64];
     __shared__ uint32_t s_base;
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(TAIL_BLOCK, 4) void k_trace_tail(TraceArgs a) {   /
 }
 
 void rt_launch_trace_tail(const TraceArgs& a, int blocks, hipStream_t s) {
-    const dim3 g(blocks), b(TAIL_BLOCK);
+    const dim3 g(blocks), b(a.grid.cell_start ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK);
     if (a.grid.cell_start) {
         if (a.depth == 0) hipLaunchKernelGGL((k_trace_tail<true, true>), g, b, 0, s, a);
         else hipLaunchKernelGGL((k_trace_tail<false, true>), g, b, 0, s, a);
