@@ -33,15 +33,21 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_{wl}")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
+def newest(pattern):
+    """gpurun merges every run's files into the same directories (rocprofv3 names them by process id): only the latest counts"""
+    files = glob.glob(pattern)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+
 for sub, suffix in (("trace", ""), ("trace_isolated", "_isolated")):
-    stats = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, f"{tag}_{wl}_kernel_stats{suffix}.csv"))
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
 for name in ("pmc_sq", "pmc_class", "pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
