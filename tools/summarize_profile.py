@@ -46,15 +46,16 @@ for sub, suffix in (("trace", ""), ("trace_isolated", "_isolated")):
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 dur = collections.defaultdict(list)
-for name in ("pmc_sq", "pmc_class", "pmc_fetch", "pmc_write"):
+dur64 = collections.defaultdict(list)
+for name in ("pmc_sq", "pmc_class", "pmc_fetch", "pmc_write", "pmc_f64"):
     for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            if name == "pmc_fetch" and r["Dispatch_Id"] not in seen:
+            if name in ("pmc_fetch", "pmc_f64") and r["Dispatch_Id"] not in seen:
                 seen.add(r["Dispatch_Id"])
-                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+                (dur if name == "pmc_fetch" else dur64)[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 out = {}
 for k, cs in pmc.items():
     if not k.startswith("k_"):
@@ -64,6 +65,32 @@ for k, cs in pmc.items():
     if dur[k]:
         out[k]["ms_under_pmc"] = sum(dur[k]) / len(dur[k])
 json.dump(out, open(os.path.join(dst, f"{tag}_{wl}_pmc.json"), "w"), indent=1, sort_keys=True)
+
+# the float64 ray-tree kernel: float64 flop executed per launch (add / mul 1, fma 2 per lane; the transcendental seeds of
+# the division and square-root expansions count 1) against the vector float64 rate of the chip
+trace = {k: c for k, c in out.items() if k.startswith("k_trace") and "SQ_INSTS_VALU_FMA_F64" in c}
+if trace:
+    kname = max(trace, key=lambda k: trace[k].get("SQ_INSTS_VALU", 0.0))
+    c = out[kname]
+    g = lambda n: c.get(n, 0.0)
+    ms64 = sum(dur64[kname]) / len(dur64[kname]) if dur64[kname] else 0.0
+    flop64 = 64.0 * (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + 2.0 * g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64"))
+    peak64 = 78.6   # TFLOP/s: 1024 SIMDs x 64 lanes x 2 flop per v_fma_f64 every 4 cycles at 2.4 GHz (measured: 3.9 cycles, tools/microbench/f64_cycles.hip)
+    entry64 = {
+        "kernel": kname, "profile": f"{tag}_{wl}", "kernel_source_hash": kernel_source_hash(),
+        "executed_fp64_flop_per_launch": flop64, "ms_under_pmc": ms64,
+        "achieved_tflops": flop64 / (ms64 * 1e-3) / 1e12 if ms64 else None, "peak_tflops": peak64,
+        "frac": flop64 / (ms64 * 1e-3) / 1e12 / peak64 if ms64 else None,
+        "fp64_share_of_valu_insts": (g("SQ_INSTS_VALU_ADD_F64") + g("SQ_INSTS_VALU_MUL_F64") + g("SQ_INSTS_VALU_FMA_F64") + g("SQ_INSTS_VALU_TRANS_F64")) / g("SQ_INSTS_VALU") if g("SQ_INSTS_VALU") else None,
+        "counters": {n: g(n) for n in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64",
+                                       "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES") if n in c},
+        "note": "latency-bound by construction: a ray's levels depend on each other, every level ends in an IEEE division "
+                "(~41 cycles per SIMD) or square root (~69) -- see tools/microbench/f64_cycles.hip",
+    }
+    path = os.path.join(dst, "trace_roofline.json")
+    allw = json.load(open(path)) if os.path.exists(path) else {}
+    allw[wl] = entry64
+    json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
 
 # the dominant kernel: the shading kernel with the most VALU instructions
 shade = {k: c for k, c in out.items() if k.startswith(("k_shade_fast", "k_shade_general"))}
