@@ -369,6 +369,19 @@ def main():
                                  "transcendental 1, fma 2, packed fma 4; counters collected on this build, see pmc_*) / the launch's duration measured "
                                  "live with HIP events on its own stream, running alone"},
         }
+        # the float64 ray-tree kernel: float64 flop executed per launch (profiles/trace_roofline.json, tools/profile.sh pass
+        # pmc_f64) / the kernel's duration measured live on its own stream, against the vector float64 rate
+        fpath = os.path.join(ROOT, "profiles", "trace_roofline.json")
+        if os.path.exists(fpath) and isolated and isolated["ms_trace"] > 0 and world == 1:
+            with open(fpath) as f:
+                t64 = json.load(f).get(args.workload)
+            if t64 and t64.get("executed_fp64_flop_per_launch"):
+                a64 = t64["executed_fp64_flop_per_launch"] / 1e12 / (isolated["ms_trace"] / 1e3)
+                out["roofline_ray_tree"] = {"bound": "valu f64 (latency-bound in practice)", "achieved": a64, "peak": t64["peak_tflops"], "unit": "TFLOP/s",
+                                            "frac": a64 / t64["peak_tflops"], "kernel": t64["kernel"], "launch_ms_isolated_live": isolated["ms_trace"],
+                                            "executed_fp64_flop_per_launch": t64["executed_fp64_flop_per_launch"],
+                                            "fp64_share_of_valu_insts": t64.get("fp64_share_of_valu_insts"),
+                                            "pmc_matches_this_build": t64.get("kernel_source_hash") == kernel_source_hash()}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene_name, W, H)
         print(json.dumps(out), flush=True)
