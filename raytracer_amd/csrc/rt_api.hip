@@ -46,6 +46,7 @@ constexpr size_t kMinArenaPixels = 65536;
 constexpr int kAsyncFirst = 32;        // bookkeeping entries (events + pinned counters) made at the first rt_render_enqueue
 constexpr int kAsyncMax = 1024;        // frames rt_render_enqueue keeps in flight before it waits for the oldest one
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
+constexpr size_t kCounterWords = (size_t)CNT_N * RT_CNT_BANKS;   // statistics: RT_CNT_BANKS banks of CNT_N words
 constexpr int kTailWork = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);   // tile counter of k_trace_tail, on a line of its own
 constexpr int kQCounts = kTailWork + (int)RT_WORK_QUEUE_STRIDE;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
@@ -106,7 +107,7 @@ struct rt_handle {
     bool no_alloc = false;           // set while rt_render_device_noalloc runs: nothing may be allocated or grown
     size_t max_band_pixels = 3840u * 2160u;
     HitDebug dbg{};
-    unsigned long long* d_counters = nullptr;  // CNT_N statistics words, directly followed by d_qcounts (one memset per band)
+    unsigned long long* d_counters = nullptr;  // RT_CNT_BANKS banks of CNT_N statistics words, directly followed by d_qcounts (one memset per band)
     uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
     unsigned long long* host_counters = nullptr;  // pinned: the band's counters land here (no staging by the runtime)
     int32_t* host_rows = nullptr;    // pinned copy of the row list on the device (the upload reads it in stream order)
@@ -267,6 +268,12 @@ void selected_rows(const rt_render_params* p, std::vector<int32_t>& rows) {
 }
 
 struct BandResult { unsigned long long c[CNT_N]; float ms_trace, ms_shade, ms_shade_main, ms_resolve; };
+// the device keeps RT_CNT_BANKS copies of the counters (rt_device.h: rt_counter); their sum is the count
+void sum_counter_banks(unsigned long long (&c)[CNT_N], const unsigned long long* banks) {
+    for (int k = 0; k < CNT_N; ++k) c[k] = 0;
+    for (int b = 0; b < RT_CNT_BANKS; ++b)
+        for (int k = 0; k < CNT_N; ++k) c[k] += banks[(size_t)b * CNT_N + k];
+}
 
 void point_tail_stack(rt_handle* h, void* mem, size_t slots) {
     char* p = (char*)mem;
@@ -364,7 +371,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     h->rows_stream_id = (const void*)st;
     { int rc = upload_rows(h, rows, n_rows, st); if (rc != RT_OK) return rc; }
     if (h->no_alloc) h->fm.accum_zero_prefix = 0;   // the scratch is shared by every handle of the device: clear what this band adds into
-    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts, st));
+    HIP_TRY(h, hipMemsetAsync(h->d_counters, 0, sizeof(unsigned long long) * kCounterWords + sizeof(uint32_t) * kQCounts, st));
     if (h->fm.accum_zero_prefix < 3 * pixels) {
         HIP_TRY(h, hipMemsetAsync(h->fm.d_accum + h->fm.accum_zero_prefix, 0, sizeof(double) * (3 * pixels - h->fm.accum_zero_prefix), st));
     }
@@ -437,14 +444,14 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipEventRecord(h->rows_ev, st));   // behind the last kernel that reads the row list
     h->rows_ev_recorded = true;
-    HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : h->host_counters, h->d_counters, sizeof(res->c), hipMemcpyDeviceToHost, st));
+    HIP_TRY(h, hipMemcpyAsync(enqueue_only ? host_counters : h->host_counters, h->d_counters, sizeof(unsigned long long) * kCounterWords, hipMemcpyDeviceToHost, st));
     HIP_TRY(h, hipEventRecord(ev[3], st));  // after the counters have landed: waiting for it is enough
     if (enqueue_only) {
         if (!debug && (d_f32 || d_u8)) h->fm.accum_zero_prefix = zero_before;  // stream order: later bands run after this resolve
         return RT_OK;
     }
     HIP_TRY(h, hipStreamSynchronize(st));
-    std::memcpy(res->c, h->host_counters, sizeof(res->c));
+    sum_counter_banks(res->c, h->host_counters);
     HIP_TRY(h, hipEventElapsedTime(&res->ms_trace, ev[0], ev[1]));
     HIP_TRY(h, hipEventElapsedTime(&res->ms_shade, ev[1], ev[2]));
     res->ms_shade_main = 0.f;
@@ -479,8 +486,10 @@ int collect_oldest(rt_handle* h) {
     HIP_TRY(h, hipEventElapsedTime(&t1m, e.ev[1], e.ev[4]));
     HIP_TRY(h, hipEventElapsedTime(&t2, e.ev[2], e.ev[3]));
     HIP_TRY(h, hipEventElapsedTime(&all, e.ev[0], e.ev[3]));
-    if (e.counters[CNT_OVERFLOW_RAY] || e.counters[CNT_OVERFLOW_SHADE] || e.counters[CNT_EXACT] > h->fm.exact_capacity) h->async_overflow = true;
-    add_band_stats(h, h->async_sum, e.counters, t0, t1, t1m, t2, e.rows);
+    unsigned long long c[CNT_N];
+    sum_counter_banks(c, e.counters);
+    if (c[CNT_OVERFLOW_RAY] || c[CNT_OVERFLOW_SHADE] || c[CNT_EXACT] > h->fm.exact_capacity) h->async_overflow = true;
+    add_band_stats(h, h->async_sum, c, t0, t1, t1m, t2, e.rows);
     h->async_sum.ms_total += all;
     return RT_OK;
 }
@@ -515,7 +524,7 @@ int take_pending(rt_handle* h, rt_handle::Pending** out) {
             auto* e = new rt_handle::Pending();
             h->pending_free.push_back(e);   // owned by the handle from here on (rt_destroy releases partly built entries too)
             for (auto& v : e->ev) HIP_TRY(h, hipEventCreate(&v));
-            HIP_TRY(h, hipHostMalloc((void**)&e->counters, sizeof(unsigned long long) * CNT_N));
+            HIP_TRY(h, hipHostMalloc((void**)&e->counters, sizeof(unsigned long long) * kCounterWords));
         }
     }
     *out = h->pending_free.back();
@@ -731,11 +740,11 @@ int rt_create(int device, rt_handle** out) {
         long v = std::atol(e);
         if (v > 0) h->max_band_pixels = (size_t)v;
     }
-    bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * CNT_N + sizeof(uint32_t) * kQCounts) == hipSuccess;
-    if (ok) h->d_qcounts = (uint32_t*)(h->d_counters + CNT_N);
+    bool ok = hipMalloc(&h->d_counters, sizeof(unsigned long long) * kCounterWords + sizeof(uint32_t) * kQCounts) == hipSuccess;
+    if (ok) h->d_qcounts = (uint32_t*)(h->d_counters + kCounterWords);
     for (auto& e : h->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&h->rows_ev, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&h->host_counters, sizeof(unsigned long long) * CNT_N) == hipSuccess;
+    ok = ok && hipHostMalloc((void**)&h->host_counters, sizeof(unsigned long long) * kCounterWords) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&h->host_rows, sizeof(int32_t) * kHostRows) == hipSuccess;
     if (ok) h->host_rows_cap = kHostRows;
     // this device's copy of the static scratch array (each GPU has its own, at its own address)

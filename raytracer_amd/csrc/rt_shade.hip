@@ -642,10 +642,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_general(ShadeArgs a) {
         }
     }
     if (lane == 0) {
-        if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
+        if (n_samples) atomicAdd(rt_counter(a.counters, CNT_SAMPLES), n_samples);
 #pragma unroll
         for (int c = 0; c < 7; ++c)
-            if (LINEAR && wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
+            if (LINEAR && wl_n[c]) atomicAdd(rt_counter(a.counters, CNT_WL_NONE + c), (unsigned long long)wl_n[c]);
     }
 }
 
@@ -1569,8 +1569,8 @@ __global__ __launch_bounds__(SHADE_BLOCK, SM > 8 ? 2 : (HAS_BOX ? RT_LB_BOX : RT
     if (lane == 0) {
 #pragma unroll
         for (int c = 0; c < 7; ++c)
-            if (wl_n[c]) atomicAdd(&a.counters[CNT_WL_NONE + c], (unsigned long long)wl_n[c]);
-        if (n_samples) atomicAdd(&a.counters[CNT_SAMPLES], n_samples);
+            if (wl_n[c]) atomicAdd(rt_counter(a.counters, CNT_WL_NONE + c), (unsigned long long)wl_n[c]);
+        if (n_samples) atomicAdd(rt_counter(a.counters, CNT_SAMPLES), n_samples);
     }
 }
 
@@ -1802,7 +1802,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
             ratio = sum * inv_n2;
         }
         const unsigned long long n_active = (unsigned long long)__popcll(__ballot(active));
-        if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_SAMPLES], (unsigned long long)(lt.point_path ? 1 : N * N) * n_active);
+        if (threadIdx.x == 0) atomicAdd(rt_counter(a.counters, CNT_SAMPLES), (unsigned long long)(lt.point_path ? 1 : N * N) * n_active);
         f3 color = F3(0.f, 0.f, 0.f);
         phong_add(color, h.nrm, ldir, h.view, m, lt, ratio);
         if (wv == 0 && active && (color.x != 0.f || color.y != 0.f || color.z != 0.f)) {
@@ -1937,7 +1937,7 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_exact(ShadeArgs a) {
     const uint32_t lane = threadIdx.x & 63;
     // the pairs asked for, listed or not: the host compares it with the capacity
     if (blockIdx.x == 0 && threadIdx.x == 0 && (listed || listed_full))
-        atomicAdd(&a.counters[CNT_EXACT], (unsigned long long)listed + (unsigned long long)listed_full);
+        atomicAdd(rt_counter(a.counters, CNT_EXACT), (unsigned long long)listed + (unsigned long long)listed_full);
     // a wave takes a batch of pairs at a time, the first batch by its own index (a wave with nothing to do leaves
     // without touching the shared counter: usually there are fewer batches than waves), the following ones from the
     // counter.  Two pairs per batch when pairs are few; when every hit is listed (a light on a surface) about a quarter

@@ -481,11 +481,11 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
     unsigned long long s_tr = wave_sum(n_traced), s_cut = wave_sum(n_cut), s_sh = wave_sum(n_shaded);
     unsigned long long s_or = wave_sum(ovf_ray), s_os = wave_sum(ovf_shade);
     if ((threadIdx.x & 63) == 0) {
-        if (s_tr) atomicAdd(&a.counters[PRIMARY ? CNT_PRIMARY : CNT_SECONDARY], s_tr);
-        if (s_cut) atomicAdd(&a.counters[CNT_DEPTH_CUT], s_cut);
-        if (s_sh) atomicAdd(&a.counters[CNT_SHADED], s_sh);
-        if (s_or) atomicAdd(&a.counters[CNT_OVERFLOW_RAY], s_or);
-        if (s_os) atomicAdd(&a.counters[CNT_OVERFLOW_SHADE], s_os);
+        if (s_tr) atomicAdd(rt_counter(a.counters, PRIMARY ? CNT_PRIMARY : CNT_SECONDARY), s_tr);
+        if (s_cut) atomicAdd(rt_counter(a.counters, CNT_DEPTH_CUT), s_cut);
+        if (s_sh) atomicAdd(rt_counter(a.counters, CNT_SHADED), s_sh);
+        if (s_or) atomicAdd(rt_counter(a.counters, CNT_OVERFLOW_RAY), s_or);
+        if (s_os) atomicAdd(rt_counter(a.counters, CNT_OVERFLOW_SHADE), s_os);
     }
 }
 
@@ -699,12 +699,12 @@ __global__ __launch_bounds__(GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK, GRID ? R
     unsigned long long s_or = wave_sum(ovf_ray), s_os = wave_sum(ovf_shade);
     unsigned long long s_pr = wave_sum(n_primary);
     if (lane == 0) {
-        if (s_pr) atomicAdd(&a.counters[CNT_PRIMARY], s_pr);
-        if (s_tr) atomicAdd(&a.counters[CNT_SECONDARY], s_tr);
-        if (s_cut) atomicAdd(&a.counters[CNT_DEPTH_CUT], s_cut);
-        if (s_sh) atomicAdd(&a.counters[CNT_SHADED], s_sh);
-        if (s_or) atomicAdd(&a.counters[CNT_OVERFLOW_RAY], s_or);
-        if (s_os) atomicAdd(&a.counters[CNT_OVERFLOW_SHADE], s_os);
+        if (s_pr) atomicAdd(rt_counter(a.counters, CNT_PRIMARY), s_pr);
+        if (s_tr) atomicAdd(rt_counter(a.counters, CNT_SECONDARY), s_tr);
+        if (s_cut) atomicAdd(rt_counter(a.counters, CNT_DEPTH_CUT), s_cut);
+        if (s_sh) atomicAdd(rt_counter(a.counters, CNT_SHADED), s_sh);
+        if (s_or) atomicAdd(rt_counter(a.counters, CNT_OVERFLOW_RAY), s_or);
+        if (s_os) atomicAdd(rt_counter(a.counters, CNT_OVERFLOW_SHADE), s_os);
     }
 }
 
