@@ -1603,8 +1603,10 @@ __global__ __launch_bounds__(SHADE_BLOCK) void k_shade_deferred(ShadeArgs a) {
     __shared__ float s_sum[SHADE_BLOCK / 64][64];
     const int wv = (int)(threadIdx.x >> 6);
     constexpr int NWV = SHADE_BLOCK / 64;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(a.work2, 1u);
+    // (a workgroup's first item is its index, the following ones come from the counter: a launch of a thousand workgroups
+    // does not begin with a thousand atomics on one word, which complete one after the other)
+    for (bool first_item = true;; first_item = false) {
+        if (threadIdx.x == 0) s_item = first_item ? blockIdx.x : gridDim.x + atomicAdd(a.work2, 1u);
         __syncthreads();
         const uint32_t item = s_item;
         __syncthreads();
