@@ -182,11 +182,19 @@ __device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD*
     // proportional to |c - o| covers.  The first three entries of a cell come with the cell's record (one round trip).
     const float wx = (float)d.x, wy = (float)d.y, wz = (float)d.z;
     double t_enter = t0;
+    // The record of the NEXT cell is requested before the current cell's entries are tested (where the walk goes next
+    // does not depend on them), so its round trip runs beside their tests.
+    uint32_t c = (uint32_t)((iz * g.n[1] + iy) * g.n[0] + ix);
+    uint4 hd, r1, r2, r3;
+    { const uint4* rec = g.cell_rec + (size_t)c * 4; hd = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; }
     for (int it = 0; it < max_steps; ++it) {
-        const uint32_t c = (uint32_t)((iz * g.n[1] + iy) * g.n[0] + ix);
-        const uint4* rec = g.cell_rec + (size_t)c * 4;
-        const uint4 hd = rec[0];
-        const uint4 r1 = rec[1], r2 = rec[2], r3 = rec[3];
+        const double t_exit = fmin(mx, fmin(my, mz));
+        const bool go_x = mx <= my && mx <= mz, go_y = !go_x && my <= mz, go_z = !go_x && !go_y;
+        const int nx = ix + (go_x ? sx : 0), ny = iy + (go_y ? sy : 0), nz = iz + (go_z ? sz : 0);
+        const bool next_in = nx >= 0 && nx < g.n[0] && ny >= 0 && ny < g.n[1] && nz >= 0 && nz < g.n[2];
+        const uint32_t cn = next_in ? (uint32_t)((nz * g.n[1] + ny) * g.n[0] + nx) : c;
+        uint4 hn, n1, n2, n3;
+        { const uint4* rec = g.cell_rec + (size_t)cn * 4; hn = rec[0]; n1 = rec[1]; n2 = rec[2]; n3 = rec[3]; }
         const uint32_t n = hd.x;
         const float olx = (float)fma(d.x, t_enter, o.x), oly = (float)fma(d.y, t_enter, o.y), olz = (float)fma(d.z, t_enter, o.z);
         const float eps_cell = 3e-7f * (fabsf(olx) + fabsf(oly) + fabsf(olz)) + 1e-7f;
@@ -205,12 +213,12 @@ __device__ __forceinline__ void nearest_in_grid(const SceneGrid& g, const SurfD*
             const int j = (int)ju;
             grid_candidate(surf[j], j, o, d, best, bs, bcode);
         }
-        const double t_exit = fmin(mx, fmin(my, mz));
         if (best < t_exit - 1e-9 * (1.0 + fabs(t_exit))) return;
+        if (!next_in) return;
         t_enter = t_exit;
-        if (mx <= my && mx <= mz) { ix += sx; if (ix < 0 || ix >= g.n[0]) return; mx += ex; }
-        else if (my <= mz) { iy += sy; if (iy < 0 || iy >= g.n[1]) return; my += ey; }
-        else { iz += sz; if (iz < 0 || iz >= g.n[2]) return; mz += ez; }
+        ix = nx; iy = ny; iz = nz;
+        mx += go_x ? ex : 0.0; my += go_y ? ey : 0.0; mz += go_z ? ez : 0.0;
+        c = cn; hd = hn; r1 = n1; r2 = n2; r3 = n3;
     }
 }
 
