@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""Development helper: reads the per-phase cycle counters of a library built with -DRT_EXP_PHASE (tools/build_variant.sh)
-after rendering one frame of a scene.  RT_AMD_LIB=raytracer_amd/librt_phase.so python tools/exp_phase.py pool_n16 3840 2160"""
+"""Development helper: reads the per-phase cycle counters of the shading kernel after rendering a scene.  The counters
+are not in the shipped source: apply tools/patches/phase_timing.patch (git apply), build the variant with
+tools/build_variant.sh phase -DRT_EXP_PHASE, revert the patch, then
+    RT_AMD_LIB=$PWD/raytracer_amd/librt_phase.so python tools/exp_phase.py pool_n16 3840 2160
+(result of this round: profiles/r03_phase_timing.txt)."""
 import ctypes
 import os
 import sys
