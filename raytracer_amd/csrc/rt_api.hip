@@ -48,7 +48,13 @@ constexpr int kAsyncMax = 1024;        // frames rt_render_enqueue keeps in flig
 constexpr int kGridMinSurfaces = 64;   // smaller scenes are tested surface by surface (staged in LDS)
 constexpr size_t kCounterWords = (size_t)CNT_N * RT_CNT_BANKS;   // statistics: RT_CNT_BANKS banks of CNT_N words
 constexpr int kTailWork = 64 + (int)(RT_WORK_QUEUES * RT_WORK_QUEUE_STRIDE);   // tile counter of k_trace_tail, on a line of its own
-constexpr int kQCounts = kTailWork + (int)RT_WORK_QUEUE_STRIDE;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
+// list counters the shading kernels append through with returning atomics -- a (wave, light) pair at a time, tens of
+// thousands per frame on scenes with touching or transparent geometry -- each on a line of its own: atomics on one
+// line complete one after the other, whichever word they address
+constexpr int kLineDeferred = kTailWork + 1 * (int)RT_WORK_QUEUE_STRIDE, kLineExact = kTailWork + 2 * (int)RT_WORK_QUEUE_STRIDE;
+constexpr int kLineFull = kTailWork + 3 * (int)RT_WORK_QUEUE_STRIDE, kLineWork3 = kTailWork + 4 * (int)RT_WORK_QUEUE_STRIDE;
+constexpr int kLineWork4 = kTailWork + 5 * (int)RT_WORK_QUEUE_STRIDE;
+constexpr int kQCounts = kTailWork + 6 * (int)RT_WORK_QUEUE_STRIDE;  // [0..7] fixed roles, [8 + d] item count of the ray queue read at depth d, [64..] work counters of k_shade_fast
 constexpr size_t kMaxArenaPixels = size_t(1) << 26;
 constexpr size_t kHostRows = 16384;    // rows of the pinned row-list staging buffer made at rt_create (grows on demand)
 
@@ -108,7 +114,7 @@ struct rt_handle {
     size_t max_band_pixels = 3840u * 2160u;
     HitDebug dbg{};
     unsigned long long* d_counters = nullptr;  // RT_CNT_BANKS banks of CNT_N statistics words, directly followed by d_qcounts (one memset per band)
-    uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [4] deferred, [5],[6] work
+    uint32_t* d_qcounts = nullptr;   // [0],[1] ray queues, [2] shade queue, [3] debug, [8 + d] ray queue of depth d, [64..] one line per busy counter (kTailWork, kLine*)
     unsigned long long* host_counters = nullptr;  // pinned: the band's counters land here (no staging by the runtime)
     int32_t* host_rows = nullptr;    // pinned copy of the row list on the device (the upload reads it in stream order)
     size_t host_rows_cap = 0;
@@ -431,12 +437,12 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
         sa.work = h->d_qcounts + 64; sa.work2 = h->d_qcounts + 6;
-        sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + 4;
+        sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + kLineDeferred;
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;
         sa.jitter_words = h->d_jitter;
-        sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + 7; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + 47;
-        sa.full_count = h->d_qcounts + 46; sa.work4 = h->d_qcounts + 45;
+        sa.exact = h->fm.d_exact; sa.exact_count = h->d_qcounts + kLineExact; sa.exact_capacity = h->fm.exact_capacity; sa.work3 = h->d_qcounts + kLineWork3;
+        sa.full_count = h->d_qcounts + kLineFull; sa.work4 = h->d_qcounts + kLineWork4;
         rt_launch_shade(sa, h->n_cu, st, ev[4]);
     }
     HIP_TRY(h, hipEventRecord(ev[2], st));
