@@ -436,7 +436,7 @@ int run_band(rt_handle* h, const rt_render_params* p, const int32_t* rows, int n
         sa.variant = (p->flags & RT_FLAG_GENERAL_SHADE) ? SHADE_GENERAL : SHADE_AUTO;
         sa.has_box = h->has_box; sa.all_opaque = h->all_opaque;
         sa.no_cull = (p->flags & RT_FLAG_NO_CULL) ? 1 : 0;
-        sa.work = h->d_qcounts + 64; sa.work2 = h->d_qcounts + 6;
+        sa.work = h->d_qcounts + 64;
         sa.deferred = h->fm.d_deferred; sa.deferred_count = h->d_qcounts + kLineDeferred;
         sa.exact_min = h->exact_min;
         sa.special = h->d_special;

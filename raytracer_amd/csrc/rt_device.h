@@ -227,7 +227,6 @@ struct ShadeArgs {
     int32_t all_opaque;  // every surface's material has transparency == 0
     int32_t no_cull;     // 1: always run the generic per-sample loop (no per-light classification)
     uint32_t* work;      // work counters of the fast kernel: RT_WORK_QUEUES of them, RT_WORK_QUEUE_STRIDE words apart (zeroed per band)
-    uint32_t* work2;     // (spare counter word, zeroed per band)
     uint2* deferred;     // (first hit of a 64-hit chunk, light) pairs left to the generic loop
     uint32_t* deferred_count;
     uint2* exact;        // (shade slot, light) pairs whose own-sphere samples need float64 (k_shade_exact), RT_NULL_HIT = void

@@ -509,9 +509,6 @@ __global__ __launch_bounds__(TRACE_BLOCK) void k_trace(TraceArgs a) {
 // serialise on the counter word).  Needs the whole surface list in one LDS tile (512-thread
 // workgroups), or the grid (single-wave workgroups: every wave takes its tiles alone).
 // ---------------------------------------------------------------------------------------
-#ifndef TAIL_DYNAMIC
-#define TAIL_DYNAMIC 1
-#endif
 template <bool PRIMARY, bool GRID>
 __global__ __launch_bounds__(GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK, GRID ? RT_TAIL_WAVES_GRID : RT_TAIL_WAVES) void k_trace_tail(TraceArgs a) {
     constexpr int TAIL_BLOCK = GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK;
@@ -554,7 +551,7 @@ __global__ __launch_bounds__(GRID ? RT_TAIL_BLOCK_GRID : RT_TAIL_BLOCK, GRID ? R
     uint32_t next_tile = blockIdx.x * WAVES + wv;
     // (grid scenes: a wave takes its tiles alone, one atomic per tile would be too many; frames with many eights per
     // workgroup are balanced well enough by equal shares, and the launch then passes no counter)
-    const bool DYNAMIC = !GRID && TAIL_DYNAMIC && a.work != nullptr;
+    const bool DYNAMIC = !GRID && a.work != nullptr;
     uint32_t ahead = 0;        // thread 0: counter value fetched for the workgroup's next refill
     bool exhausted = false;    // DYNAMIC: the last refill found the tiles used up
     uint32_t idx = 0;
